@@ -1,0 +1,184 @@
+"""ctypes binding of libhmcgibbs.so (C ABI: include/hmcg.h).
+
+The library is the product: hand-written HIP kernels for gfx950.  There is no
+CPU fallback anywhere in this package -- if the shared object is missing or no
+GPU is usable, the compute entry points raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libhmcgibbs.so")
+
+HMCG_MAXH = 8
+HMCG_MAXK = 8
+FLAG_RESUME = 1
+
+ST_BAD_INVGAMMA, ST_EMIS_UNDERFLOW, ST_NONFINITE, ST_GAMMA_CAP, ST_BAD_T = 1, 2, 4, 8, 16
+
+EXPORTS = ("hmcg_version", "hmcg_device_count", "hmcg_last_error", "hmcg_shutdown",
+           "hmcg_estimate_batch", "hmcg_estimate_batch_device")
+
+
+class HmcgError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("W", C.c_int32), ("K", C.c_int32), ("ldY", C.c_int32),
+                ("max_T", C.c_int32), ("burnin", C.c_int32), ("nrun", C.c_int32), ("H", C.c_int32),
+                ("horizons", C.c_int32 * HMCG_MAXH), ("seed", C.c_uint64), ("window_base", C.c_uint32),
+                ("device", C.c_int32), ("flags", C.c_int32), ("threads_per_window", C.c_int32),
+                ("sweep_base", C.c_int32), ("reserved0", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double)]
+
+
+class Extras(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("x_init", C.c_void_p),
+                ("x_final", C.c_void_p), ("pif_final", C.c_void_p), ("xstate", C.c_void_p), ("sumacc", C.c_void_p), ("window_ids", C.c_void_p)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int32), ("threads_per_window", C.c_int32),
+                ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32)]
+
+
+_LIB = None
+
+
+def build(force=False):
+    """Compile libhmcgibbs.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("hmcg.hip", "gibbs_device.hpp")] + \
+           [os.path.join(HERE, "..", "include", "hmcg.h")]
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-B", "libhmcgibbs.so"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return SO_PATH
+
+
+def load():
+    """Load the shared object (no GPU needed for this; compute calls need one)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise HmcgError("libhmcgibbs.so is not built (%s); run __graft_entry__.build() -- "
+                            "this package has no CPU fallback" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        L.hmcg_version.restype = C.c_int
+        L.hmcg_device_count.restype = C.c_int
+        L.hmcg_last_error.restype = C.c_char_p
+        L.hmcg_shutdown.restype = None
+        L.hmcg_estimate_batch.restype = C.c_int
+        L.hmcg_estimate_batch_device.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().hmcg_last_error().decode("utf-8", "replace")
+        raise HmcgError("libhmcgibbs rc=%d: %s" % (rc, msg))
+
+
+def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base=0, device=0, flags=0,
+                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0):
+    cfg = Config()
+    cfg.struct_size = C.sizeof(Config)
+    cfg.W, cfg.K, cfg.ldY, cfg.max_T = int(W), int(K), int(ldY), int(max_T)
+    cfg.burnin, cfg.nrun, cfg.H = int(burnin), int(nrun), len(horizons)
+    if len(horizons) > HMCG_MAXH:
+        raise ValueError("at most %d horizons" % HMCG_MAXH)
+    for i, h in enumerate(horizons):
+        cfg.horizons[i] = int(h)
+    cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    cfg.window_base = int(window_base)
+    cfg.device, cfg.flags = int(device), int(flags)
+    cfg.threads_per_window, cfg.sweep_base = int(threads_per_window), int(sweep_base)
+    cfg.alpha, cfg.nu = float(alpha), float(nu)
+    return cfg
+
+
+def _np_ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, window_base=0, device=0,
+                        threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
+                        resume_state=None, sweep_base=0, window_ids=None):
+    """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
+    C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
+    A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,)."""
+    L = load()
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    W, ldY = Y.shape
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    H = len(horizons)
+    NS = 3 * K + K * K + 2 * H
+    yr = None if yreal is None else np.ascontiguousarray(yreal, dtype=np.float64).reshape(W, H)
+    out = {}
+    if want_draws:
+        out["mu"] = np.zeros((W, K, nrun)); out["sig2"] = np.zeros((W, K, nrun))
+        out["A"] = np.zeros((W, K, K, nrun)); out["pi_end"] = np.zeros((W, K, nrun))
+        out["fcast"] = np.zeros((W, 2 * H, nrun))
+    out["summary"] = np.zeros((W, NS))
+    out["status"] = np.zeros(W, dtype=np.int32)
+    ex = Extras()
+    ex.struct_size = C.sizeof(Extras)
+    flags = 0
+    if x_init is not None:
+        xi = np.ascontiguousarray(x_init, dtype=np.int32).reshape(W, ldY)
+        ex.x_init = xi.ctypes.data
+    if window_ids is not None:
+        wid = np.ascontiguousarray(window_ids, dtype=np.uint32).reshape(W)
+        ex.window_ids = wid.ctypes.data
+    if want_state:
+        out["x_final"] = np.zeros((W, ldY), dtype=np.int32)
+        out["pif_final"] = np.zeros((W, ldY, K))
+        out["xstate"] = np.zeros((W, ldY), dtype=np.uint8)
+        out["sumacc"] = np.zeros((W, NS))
+        ex.x_final = out["x_final"].ctypes.data
+        ex.pif_final = out["pif_final"].ctypes.data
+        ex.xstate = out["xstate"].ctypes.data
+        ex.sumacc = out["sumacc"].ctypes.data
+    if resume_state is not None:
+        flags |= FLAG_RESUME
+        out["xstate"] = np.ascontiguousarray(resume_state["xstate"], dtype=np.uint8).copy()
+        out["sumacc"] = np.ascontiguousarray(resume_state["sumacc"], dtype=np.float64).copy()
+        out["status"] = np.ascontiguousarray(resume_state["status"], dtype=np.int32).copy()
+        ex.xstate = out["xstate"].ctypes.data
+        ex.sumacc = out["sumacc"].ctypes.data
+    cfg = make_config(W, K, ldY, int(T.max()), burnin, nrun, horizons, seed, window_base, device, flags,
+                      threads_per_window, sweep_base, alpha, nu)
+    tm = Timing()
+    rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
+                               _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),
+                               _np_ptr(out.get("pi_end")), _np_ptr(out.get("fcast")), _np_ptr(out["summary"]),
+                               _np_ptr(out["status"]), C.byref(ex), C.byref(tm))
+    _check(rc)
+    out["kernel_ms"] = tm.kernel_ms
+    out["threads_per_window"] = tm.threads_per_window
+    out["steps_per_thread"] = tm.steps_per_thread
+    out["lds_bytes"] = tm.lds_bytes
+    return out
+
+
+def estimate_batch_device(cfg, dY, dT, dyreal, dmu, dsig2, dA, dpi_end, dfcast, dsummary, dstatus,
+                          extras=None, stream=None, timed=True):
+    """hmcg_estimate_batch_device over raw device pointers (ints, e.g. torch
+    tensor.data_ptr()).  Returns the Timing struct when timed, else None."""
+    L = load()
+    tm = Timing() if timed else None
+
+    def vp(x):
+        return None if not x else C.c_void_p(int(x))
+
+    rc = L.hmcg_estimate_batch_device(C.byref(cfg), vp(dY), vp(dT), vp(dyreal), vp(dmu), vp(dsig2), vp(dA),
+                                      vp(dpi_end), vp(dfcast), vp(dsummary), vp(dstatus),
+                                      C.byref(extras) if extras is not None else None, vp(stream),
+                                      C.byref(tm) if timed else None)
+    _check(rc)
+    return tm

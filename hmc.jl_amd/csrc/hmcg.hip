@@ -1,0 +1,288 @@
+// hmcg.hip -- host side of libhmcgibbs.so (C ABI in include/hmcg.h).
+// Owns the lazily created per-process context (stream, events), validates
+// arguments, picks the kernel instantiation for (K, max_T, threads_per_window)
+// and launches the persistent per-window sweep kernel.  No CPU compute path
+// exists here: without a HIP device every compute entry returns HMCG_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "gibbs_device.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::mutex g_mu;
+
+void set_err(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                            \
+        }                                                                              \
+    } while (0)
+
+struct Context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+Context g_ctx;
+
+int ensure_context(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_err("no HIP device available (libhmcgibbs has no CPU fallback)");
+        return HMCG_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_err("device %d out of range (count %d)", device, n);
+        return HMCG_E_BADARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (g_ctx.device != device) {
+        if (g_ctx.stream) { (void)hipStreamDestroy(g_ctx.stream); (void)hipEventDestroy(g_ctx.ev0); (void)hipEventDestroy(g_ctx.ev1); }
+        g_ctx = Context{};
+        HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&g_ctx.ev0));
+        HIP_TRY(hipEventCreate(&g_ctx.ev1));
+        g_ctx.device = device;
+    }
+    return 0;
+}
+
+using KernelFn = void (*)(const hmcg::KernelParams);
+
+struct Variant {
+    int K, L, NT;
+    KernelFn fn;
+};
+
+#define HMCG_VARIANT(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_> }
+const Variant g_variants[] = {
+    HMCG_VARIANT(2, 1, 256), HMCG_VARIANT(2, 2, 256), HMCG_VARIANT(2, 4, 256), HMCG_VARIANT(2, 8, 256),
+    HMCG_VARIANT(3, 1, 256), HMCG_VARIANT(3, 2, 256), HMCG_VARIANT(3, 4, 256), HMCG_VARIANT(3, 8, 256),
+    HMCG_VARIANT(3, 16, 256),
+    HMCG_VARIANT(3, 2, 512), HMCG_VARIANT(3, 8, 128),
+    HMCG_VARIANT(4, 1, 256), HMCG_VARIANT(4, 2, 256), HMCG_VARIANT(4, 4, 256), HMCG_VARIANT(4, 8, 256),
+};
+
+const Variant* pick_variant(int K, int maxT, int nt_req)
+{
+    const int nt = nt_req > 0 ? nt_req : 256;
+    const Variant* best = nullptr;
+    for (const Variant& v : g_variants) {
+        if (v.K != K || v.NT != nt || v.L * v.NT < maxT) continue;
+        if (!best || v.L < best->L) best = &v;
+    }
+    return best;
+}
+
+int validate(const hmcg_config* cfg)
+{
+    if (!cfg) { set_err("cfg is NULL"); return HMCG_E_BADARG; }
+    if (cfg->struct_size != (int32_t)sizeof(hmcg_config)) {
+        set_err("hmcg_config.struct_size %d != %d", cfg->struct_size, (int)sizeof(hmcg_config));
+        return HMCG_E_BADARG;
+    }
+    if (cfg->W < 1 || cfg->K < 2 || cfg->K > HMCG_MAXK || cfg->ldY < 2 || cfg->burnin < 0 || cfg->nrun < 0 ||
+        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0) {
+        set_err("bad hmcg_config (W=%d K=%d ldY=%d max_T=%d burnin=%d nrun=%d H=%d)", cfg->W, cfg->K, cfg->ldY,
+                cfg->max_T, cfg->burnin, cfg->nrun, cfg->H);
+        return HMCG_E_BADARG;
+    }
+    for (int h = 0; h < cfg->H; ++h)
+        if (cfg->horizons[h] < 0) { set_err("negative horizon"); return HMCG_E_BADARG; }
+    return 0;
+}
+
+int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, const double* dyreal, double* dmu,
+                  double* dsig2, double* dA, double* dpi_end, double* dfcast, double* dsummary, int32_t* dstatus,
+                  const hmcg_extras* ex, hipStream_t stream, hmcg_timing* timing)
+{
+    if (!dY || !dT || !dstatus) { set_err("Y, T and status are required"); return HMCG_E_BADARG; }
+    if (ex && ex->struct_size != (int32_t)sizeof(hmcg_extras)) { set_err("hmcg_extras.struct_size mismatch"); return HMCG_E_BADARG; }
+    const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
+    if (resume && !(ex && ex->xstate)) { set_err("HMCG_FLAG_RESUME needs extras.xstate"); return HMCG_E_BADARG; }
+    const int maxT = cfg->max_T > 0 ? cfg->max_T : cfg->ldY;
+    const Variant* v = pick_variant(cfg->K, maxT, cfg->threads_per_window);
+    if (!v) {
+        set_err("no kernel for K=%d max_T=%d threads_per_window=%d", cfg->K, maxT, cfg->threads_per_window);
+        return HMCG_E_UNSUPPORTED;
+    }
+    hmcg::KernelParams p{};
+    p.Y = dY; p.T = dT; p.yreal = dyreal;
+    p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H; p.nrun = cfg->nrun;
+    p.sweep_begin = cfg->sweep_base;
+    p.sweep_end = cfg->burnin + cfg->nrun;
+    p.keep_from = cfg->burnin;
+    p.resume = resume ? 1 : 0;
+    p.final_launch = 1;
+    for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
+    p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.window_base = cfg->window_base;
+    p.alpha = cfg->alpha > 0.0 ? cfg->alpha : 1.0;
+    p.nu = cfg->nu > 0.0 ? cfg->nu : 1.0;
+    p.mu = dmu; p.sig2 = dsig2; p.A = dA; p.pi_end = dpi_end; p.fcast = dfcast; p.summary = dsummary;
+    p.status = dstatus;
+    if (ex) { p.x_init = ex->x_init; p.x_final = ex->x_final; p.pif_final = ex->pif_final; p.xstate = ex->xstate; p.sumacc = ex->sumacc; p.window_ids = ex->window_ids; }
+    if (p.sweep_end < p.sweep_begin) { set_err("sweep_base beyond burnin+nrun"); return HMCG_E_BADARG; }
+
+    if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
+    const size_t dyn = sizeof(double) * (size_t)v->NT * v->L;
+    if (timing) HIP_TRY(hipEventRecord(g_ctx.ev0, stream));
+    hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)v->NT), dyn, stream, p);
+    HIP_TRY(hipGetLastError());
+    if (timing) {
+        HIP_TRY(hipEventRecord(g_ctx.ev1, stream));
+        HIP_TRY(hipEventSynchronize(g_ctx.ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1));
+        timing->kernel_ms = ms;
+        timing->launches = 1;
+        timing->threads_per_window = v->NT;
+        timing->steps_per_thread = v->L;
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(v->fn)) == hipSuccess)
+            timing->lds_bytes = (int32_t)(fa.sharedSizeBytes + dyn);
+    }
+    return 0;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return (int)hipMalloc((void**)&p, n * sizeof(T)); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int hmcg_version(void) { return HMCG_VERSION; }
+
+int hmcg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* hmcg_last_error(void) { return g_err; }
+
+void hmcg_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx.stream) {
+        (void)hipStreamSynchronize(g_ctx.stream);
+        (void)hipStreamDestroy(g_ctx.stream);
+        (void)hipEventDestroy(g_ctx.ev0);
+        (void)hipEventDestroy(g_ctx.ev1);
+    }
+    g_ctx = Context{};
+}
+
+int hmcg_estimate_batch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, const double* dyreal,
+                               double* dmu, double* dsig2, double* dA, double* dpi_end, double* dfcast,
+                               double* dsummary, int32_t* dstatus, const hmcg_extras* dextras, void* stream,
+                               hmcg_timing* timing)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_err[0] = 0;
+    int rc = validate(cfg);
+    if (rc) return rc;
+    rc = ensure_context(cfg->device);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+    return launch_device(cfg, dY, dT, dyreal, dmu, dsig2, dA, dpi_end, dfcast, dsummary, dstatus, dextras, s, timing);
+}
+
+int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* T, const double* yreal, double* mu,
+                        double* sig2, double* A, double* pi_end, double* fcast, double* summary, int32_t* status,
+                        const hmcg_extras* extras, hmcg_timing* timing)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_err[0] = 0;
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!Y || !T) { set_err("Y and T are required"); return HMCG_E_BADARG; }
+    rc = ensure_context(cfg->device);
+    if (rc) return rc;
+    const size_t W = (size_t)cfg->W, K = (size_t)cfg->K, ld = (size_t)cfg->ldY, H = (size_t)cfg->H, nrun = (size_t)cfg->nrun;
+    const size_t NS = 3 * K + K * K + 2 * H;
+    hipStream_t s = g_ctx.stream;
+    DevBuf<double> dY, dyr, dmu, dsig, dA, dpe, dfc, dsum, dpif, dacc;
+    DevBuf<int32_t> dT, dst, dxi, dxf;
+    DevBuf<uint8_t> dxs;
+    DevBuf<uint32_t> dwid;
+#define ALLOC(buf, n) do { if ((buf).alloc(n) != 0) { set_err("hipMalloc of %zu elements failed", (size_t)(n)); return HMCG_E_NOMEM; } } while (0)
+    ALLOC(dY, W * ld); ALLOC(dT, W); ALLOC(dst, W);
+    HIP_TRY(hipMemcpyAsync(dY.p, Y, sizeof(double) * W * ld, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dT.p, T, sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
+    if (yreal && H) { ALLOC(dyr, W * H); HIP_TRY(hipMemcpyAsync(dyr.p, yreal, sizeof(double) * W * H, hipMemcpyHostToDevice, s)); }
+    if (mu && nrun) ALLOC(dmu, W * K * nrun);
+    if (sig2 && nrun) ALLOC(dsig, W * K * nrun);
+    if (A && nrun) ALLOC(dA, W * K * K * nrun);
+    if (pi_end && nrun) ALLOC(dpe, W * K * nrun);
+    if (fcast && nrun && H) ALLOC(dfc, W * 2 * H * nrun);
+    if (summary) ALLOC(dsum, W * NS);
+    hmcg_extras dex{};
+    dex.struct_size = (int32_t)sizeof(hmcg_extras);
+    const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
+    if (extras) {
+        if (extras->struct_size != (int32_t)sizeof(hmcg_extras)) { set_err("hmcg_extras.struct_size mismatch"); return HMCG_E_BADARG; }
+        if (extras->x_init) { ALLOC(dxi, W * ld); HIP_TRY(hipMemcpyAsync(dxi.p, extras->x_init, sizeof(int32_t) * W * ld, hipMemcpyHostToDevice, s)); dex.x_init = dxi.p; }
+        if (extras->x_final) { ALLOC(dxf, W * ld); HIP_TRY(hipMemsetAsync(dxf.p, 0, sizeof(int32_t) * W * ld, s)); dex.x_final = dxf.p; }
+        if (extras->pif_final) { ALLOC(dpif, W * ld * K); HIP_TRY(hipMemsetAsync(dpif.p, 0, sizeof(double) * W * ld * K, s)); dex.pif_final = dpif.p; }
+        if (extras->xstate) {
+            ALLOC(dxs, W * ld);
+            if (resume) HIP_TRY(hipMemcpyAsync(dxs.p, extras->xstate, W * ld, hipMemcpyHostToDevice, s));
+            else HIP_TRY(hipMemsetAsync(dxs.p, 0, W * ld, s));
+            dex.xstate = dxs.p;
+        }
+        if (extras->window_ids) { ALLOC(dwid, W); HIP_TRY(hipMemcpyAsync(dwid.p, extras->window_ids, sizeof(uint32_t) * W, hipMemcpyHostToDevice, s)); dex.window_ids = dwid.p; }
+        if (extras->sumacc) {
+            ALLOC(dacc, W * NS);
+            if (resume) HIP_TRY(hipMemcpyAsync(dacc.p, extras->sumacc, sizeof(double) * W * NS, hipMemcpyHostToDevice, s));
+            dex.sumacc = dacc.p;
+        }
+    }
+    if (resume && status) HIP_TRY(hipMemcpyAsync(dst.p, status, sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
+    else if (resume) HIP_TRY(hipMemsetAsync(dst.p, 0, sizeof(int32_t) * W, s));
+#undef ALLOC
+    rc = launch_device(cfg, dY.p, dT.p, dyr.p, dmu.p, dsig.p, dA.p, dpe.p, dfc.p, dsum.p, dst.p, &dex, s, timing);
+    if (rc) return rc;
+#define D2H(dst_, src_, n) do { if ((dst_) && (src_)) HIP_TRY(hipMemcpyAsync((dst_), (src_), (n), hipMemcpyDeviceToHost, s)); } while (0)
+    D2H(mu, dmu.p, sizeof(double) * W * K * nrun);
+    D2H(sig2, dsig.p, sizeof(double) * W * K * nrun);
+    D2H(A, dA.p, sizeof(double) * W * K * K * nrun);
+    D2H(pi_end, dpe.p, sizeof(double) * W * K * nrun);
+    D2H(fcast, dfc.p, sizeof(double) * W * 2 * H * nrun);
+    D2H(summary, dsum.p, sizeof(double) * W * NS);
+    D2H(status, dst.p, sizeof(int32_t) * W);
+    if (extras) {
+        D2H(extras->x_final, dxf.p, sizeof(int32_t) * W * ld);
+        D2H(extras->pif_final, dpif.p, sizeof(double) * W * ld * K);
+        D2H(extras->xstate, dxs.p, W * ld);
+        D2H(extras->sumacc, dacc.p, sizeof(double) * W * NS);
+    }
+#undef D2H
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+/*
+ * hmcg.h -- C ABI of libhmcgibbs.so: batched Gibbs-sampled Gaussian-HMM estimation
+ * on AMD MI355X (gfx950).  This is the drop-in boundary for the data-parallel hot
+ * path of joe5saia/Hmc.jl.
+ *
+ * The reference has no FFI of its own: its boundary is the Julia function surface
+ * of `module Hmc`.  What each entry point replaces (reference file:line):
+ *
+ *   hmcg_estimate_batch[_device]   W x { Hmc.estimatemodel(opt)       src/Hmc.jl:850-865
+ *                                        -> makeParams                src/Hmc.jl:161-195
+ *                                        -> HyperParams(Y,D)          src/Hmc.jl:132-142
+ *                                        -> gibbssample!/gibbssweep!  src/Hmc.jl:486-562
+ *                                           (update_mu_sigma :231-336, update_beta :338-348,
+ *                                            update_rho :350-356, update_A :358-369,
+ *                                            forwardupdate_P :371-440, backwardupdate_P :442-457
+ *                                            [only pib[end,:] is produced], sort :501-513,
+ *                                            update_X :459-484)
+ *                                        -> forecast per draw         src/Hmc.jl:658-667, 860-862 }
+ *                                  and the per-window means that runaggregate
+ *                                  (src/Hmc.jl:1025-1078) takes over the 5-digit-rounded
+ *                                  per-draw CSV rows of basicsave (src/Hmc.jl:707-722).
+ *   W windows in one call          replace the SLURM array fan-out, one process per
+ *                                  window (slurmscripts/base_estimation.sh:5,17).
+ *
+ * Conventions: plain C structs, fixed-width ints, no C++ types or exceptions cross
+ * the boundary.  Return 0 on success, negative on API misuse (HMCG_E_*), positive
+ * = hipError_t of a failed HIP call.  Per-window numerical trouble is reported in
+ * status[w] (HMCG_ST_* bits), never as a call failure.  The caller allocates and
+ * owns every buffer; the library keeps no caller pointer after return.  The host
+ * entry is blocking.  Calls are serialised by an internal mutex.  There is NO CPU
+ * fallback: without a usable GPU every compute entry fails with HMCG_E_NODEVICE.
+ *
+ * Array layouts are the reference's Julia (column-major) layouts with the window
+ * index appended as the slowest dimension:
+ *   mu, sig2, pi_end : Julia (nrun, K, W)      elem (d,k,w)   at d + nrun*(k + K*w)
+ *   A                : Julia (nrun, K, K, W)   elem (d,i,j,w) at d + nrun*(i + K*(j + K*w))
+ *   fcast            : Julia (nrun, 2H, W)     cols forecast_h, forecast_error_h per horizon
+ *   summary          : Julia (3K+K*K+2H, W)    means over draws of round(x; digits=5), rows
+ *                      mu(K) | sig2(K) | pi_end(K) | A(:) column-major (K*K) | fcast(2H)
+ *   Y                : window-major panel, row w holds Y_w[0..T[w]-1], leading dim ldY
+ *   yreal            : (H, W): realised value rawdata[endIndex+h] per horizon (NaN if unknown)
+ * "sig2" holds the VARIANCE draws (the reference's `sigma` arrays hold variances).
+ * States are labelled 0..K-1 here (1..K in Julia).
+ */
+#ifndef HMCG_H
+#define HMCG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMCG_VERSION 100
+#define HMCG_MAXH 8
+#define HMCG_MAXK 8
+
+/* API-misuse return codes */
+#define HMCG_E_BADARG   (-1)
+#define HMCG_E_NODEVICE (-2)
+#define HMCG_E_UNSUPPORTED (-3) /* (K, max_T) combination has no compiled kernel */
+#define HMCG_E_NOMEM    (-4)
+
+/* status[w] bits */
+#define HMCG_ST_BAD_INVGAMMA   1 /* a<=0 or b<=0 in the InvGamma update: old variance kept (src/Hmc.jl:319-329) */
+#define HMCG_ST_EMIS_UNDERFLOW 2 /* all K emission pdfs underflowed (or zero normaliser) at some step: uniform step substituted (reference would throw, src/Hmc.jl:435) */
+#define HMCG_ST_NONFINITE      4 /* non-finite observation: window skipped, outputs untouched */
+#define HMCG_ST_GAMMA_CAP      8 /* gamma rejection sampler hit its attempt cap */
+#define HMCG_ST_BAD_T         16 /* T[w] < 2 or T[w] > max_T: window skipped */
+
+/* flags */
+#define HMCG_FLAG_RESUME 1  /* chain state (extras.xstate) is loaded instead of the makeParams init; sweep numbering continues at sweep_base */
+
+typedef struct hmcg_config {
+    int32_t struct_size;     /* = sizeof(hmcg_config), for ABI evolution */
+    int32_t W;               /* windows in this call */
+    int32_t K;               /* states, 2..HMCG_MAXK   (estopt.D, src/Hmc.jl:32) */
+    int32_t ldY;             /* leading dimension of the Y panel, >= max_T */
+    int32_t max_T;           /* max over w of T[w] (0: use ldY) */
+    int32_t burnin;          /* discarded sweeps (estopt.burnin, src/Hmc.jl:33) */
+    int32_t nrun;            /* kept sweeps      (estopt.Nrun,   src/Hmc.jl:34) */
+    int32_t H;               /* number of forecast horizons, 0..HMCG_MAXH */
+    int32_t horizons[HMCG_MAXH]; /* estopt.horizons, src/Hmc.jl:31 */
+    uint64_t seed;           /* estopt.seed (src/Hmc.jl:41,59); Philox key */
+    uint32_t window_base;    /* RNG stream id of window 0 of this call; window w uses window_base+w,
+                                so a sharded run reproduces the unsharded one */
+    int32_t device;          /* HIP device ordinal */
+    int32_t flags;           /* HMCG_FLAG_* */
+    int32_t threads_per_window; /* 0 = auto (256); 128/256/512 */
+    int32_t sweep_base;      /* global index of the first sweep of this call (0 unless resuming) */
+    int32_t reserved0;
+    double alpha;            /* InvGamma prior sample size, 0 -> 1.0 (HyperParams(Y,D), src/Hmc.jl:137) */
+    double nu;               /* Normal prior sample size,   0 -> 1.0 (src/Hmc.jl:140) */
+} hmcg_config;
+
+/* Optional debug / teacher-forcing / checkpoint buffers (all may be NULL).  Pointer
+ * residency follows the entry point (host pointers for hmcg_estimate_batch, device
+ * pointers for hmcg_estimate_batch_device). */
+typedef struct hmcg_extras {
+    int32_t struct_size;
+    int32_t reserved;
+    const int32_t* x_init;   /* [W][ldY] initial states (0-based) instead of makeParams' argmax-pdf init */
+    int32_t* x_final;        /* [W][ldY] states after the last sweep */
+    double* pif_final;       /* [W][ldY][K] UNSORTED filtered probabilities pif[t,:] of the last sweep */
+    uint8_t* xstate;         /* [W][ldY] chain state for HMCG_FLAG_RESUME: read at start when the flag is
+                                set, written at the end whenever non-NULL (checkpoint) */
+    double* sumacc;          /* [W][3K+K*K+2H] running sums behind `summary` (resume across calls) */
+    const uint32_t* window_ids; /* [W] explicit RNG stream ids (NULL: window_base + w); lets a sharded /
+                                   load-balanced run reproduce the unsharded one window for window */
+} hmcg_extras;
+
+typedef struct hmcg_timing {
+    double kernel_ms;        /* HIP-event time of the sweep kernel(s) on the launch stream */
+    int32_t launches;
+    int32_t threads_per_window;
+    int32_t steps_per_thread;
+    int32_t lds_bytes;
+} hmcg_timing;
+
+int hmcg_version(void);
+int hmcg_device_count(void);          /* number of usable HIP devices (0 if none) */
+const char* hmcg_last_error(void);    /* thread-local, never NULL */
+void hmcg_shutdown(void);             /* releases the library's streams/workspaces */
+
+/* Host-buffer entry: copies Y/T/yreal to the device, runs, copies results back.
+ * Any output pointer may be NULL (that output is not produced). */
+int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* T, const double* yreal,
+                        double* mu, double* sig2, double* A, double* pi_end, double* fcast,
+                        double* summary, int32_t* status, const hmcg_extras* extras, hmcg_timing* timing);
+
+/* Device-buffer entry: every data pointer is HBM-resident on cfg->device.  Work is
+ * enqueued on `stream` (a hipStream_t; NULL = the library's own stream).  The call
+ * returns after enqueueing unless `timing` is non-NULL, in which case it waits for
+ * completion and fills it.  status must be zero-initialised by the caller or is
+ * zeroed by the library when HMCG_FLAG_RESUME is not set. */
+int hmcg_estimate_batch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, const double* dyreal,
+                               double* dmu, double* dsig2, double* dA, double* dpi_end, double* dfcast,
+                               double* dsummary, int32_t* dstatus, const hmcg_extras* dextras,
+                               void* stream, hmcg_timing* timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMCG_H */
