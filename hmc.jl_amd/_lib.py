@@ -33,7 +33,7 @@ class Config(C.Structure):
                 ("max_T", C.c_int32), ("burnin", C.c_int32), ("nrun", C.c_int32), ("H", C.c_int32),
                 ("horizons", C.c_int32 * HMCG_MAXH), ("seed", C.c_uint64), ("window_base", C.c_uint32),
                 ("device", C.c_int32), ("flags", C.c_int32), ("threads_per_window", C.c_int32),
-                ("sweep_base", C.c_int32), ("reserved0", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double)]
+                ("sweep_base", C.c_int32), ("sweep_count", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double)]
 
 
 class Extras(C.Structure):
@@ -60,6 +60,33 @@ def build(force=False):
     return SO_PATH
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7) next to libtorch_hip.so and resolves it by FILE name, while
+    libhmcgibbs.so needs the SONAME.  If ours were loaded first (binding the system
+    /opt/rocm runtime), a later `import torch` would bring a second runtime into the process
+    and neither could use the other's device pointers or streams.  So when torch is
+    installed, its copy is made resident first; libhmcgibbs then binds to it by SONAME, and
+    a later `import torch` finds the same file already loaded.  Without torch (C or Julia
+    callers) the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared object (no GPU needed for this; compute calls need one)."""
     global _LIB
@@ -67,6 +94,7 @@ def load():
         if not os.path.exists(SO_PATH):
             raise HmcgError("libhmcgibbs.so is not built (%s); run __graft_entry__.build() -- "
                             "this package has no CPU fallback" % SO_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(SO_PATH)
         L.hmcg_version.restype = C.c_int
         L.hmcg_device_count.restype = C.c_int
@@ -85,7 +113,7 @@ def _check(rc):
 
 
 def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base=0, device=0, flags=0,
-                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0):
+                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0, sweep_count=0):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.W, cfg.K, cfg.ldY, cfg.max_T = int(W), int(K), int(ldY), int(max_T)
@@ -98,6 +126,7 @@ def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base
     cfg.window_base = int(window_base)
     cfg.device, cfg.flags = int(device), int(flags)
     cfg.threads_per_window, cfg.sweep_base = int(threads_per_window), int(sweep_base)
+    cfg.sweep_count = int(sweep_count)
     cfg.alpha, cfg.nu = float(alpha), float(nu)
     return cfg
 
@@ -108,7 +137,7 @@ def _np_ptr(a):
 
 def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, window_base=0, device=0,
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
-                        resume_state=None, sweep_base=0, window_ids=None):
+                        resume_state=None, sweep_base=0, window_ids=None, sweep_count=0):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,)."""
@@ -152,7 +181,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         ex.xstate = out["xstate"].ctypes.data
         ex.sumacc = out["sumacc"].ctypes.data
     cfg = make_config(W, K, ldY, int(T.max()), burnin, nrun, horizons, seed, window_base, device, flags,
-                      threads_per_window, sweep_base, alpha, nu)
+                      threads_per_window, sweep_base, alpha, nu, sweep_count)
     tm = Timing()
     rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
                                _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),

@@ -351,12 +351,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int l = 0; l < L; ++l) if (valid[l]) x[l] = p.x_init[(size_t)w * p.ldY + t0 + l];
     } else {
-        // ---- makeParams (src/Hmc.jl:161-195): mu spread around the median, "sigma"=std(Y), X=argmax pdf
-        part = 0.0;
-#pragma unroll
-        for (int l = 0; l < L; ++l) part += valid[l] ? (y[l] - ymean) * (y[l] - ymean) : 0.0;
-        const double ss = block_sum<NW>(part, sh.bred, wave, lane);
-        const double sd0 = sqrt(ss / (double)(T - 1));
+        // ---- makeParams (src/Hmc.jl:161-195): mu spread around the median, X = argmax pdf.
+        // The initial "sigma" (= std(Y), :177) is the same for every state and is overwritten by the
+        // first sweep before any other use, so argmax pdf == nearest initial mean (first index on
+        // ties) and std(Y) itself is never needed.  Distances, not pdf values, are compared so the
+        // decision does not depend on the exp implementation (see oracle/hmc_oracle.c chain_init).
         double lmin = 1.0e308, lmax = -1.0e308;
 #pragma unroll
         for (int l = 0; l < L; ++l) if (valid[l]) { lmin = fmin(lmin, y[l]); lmax = fmax(lmax, y[l]); }
@@ -390,13 +389,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             int best = 0;
-            double bz = (y[l] - mu0[0]) / sd0;
-            double bv = exp(-(bz * bz) / 2.0) * INVSQRT2PI / sd0;
+            double bd = fabs(y[l] - mu0[0]);
 #pragma unroll
             for (int k = 1; k < K; ++k) {
-                const double z = (y[l] - mu0[k]) / sd0;
-                const double v = exp(-(z * z) / 2.0) * INVSQRT2PI / sd0;
-                if (v > bv) { bv = v; best = k; }
+                const double d = fabs(y[l] - mu0[k]);
+                if (d < bd) { bd = d; best = k; }
             }
             x[l] = valid[l] ? best : 0;
         }
@@ -596,10 +593,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 f[l][s] = exp(-(z * z) / 2.0) * coef[s];
                 fm = fmax(fm, f[l][s]);
             }
-            if (valid[l] && !(fm >= 1e-300)) {       // all pdfs underflowed: uniform step
-                st |= HMCG_ST_EMIS_UNDERFLOW;
+            if (!(fm >= 1e-300)) {
+                // every pdf underflowed: treat the observation as missing (f = 1) and flag the window
+                if (valid[l]) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
-                for (int s = 0; s < K; ++s) f[l][s] = -1.0;   // marker
+                for (int s = 0; s < K; ++s) f[l][s] = 1.0;
             } else {
                 const int e = -ilogb(fm) - 1;        // exact power-of-two scaling of the step
 #pragma unroll
@@ -616,27 +614,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         for (int l = 0; l < L; ++l) {
             if (valid[l]) {
                 double N[KK];
-                if (f[l][0] < 0.0) {
-                    // uniform step: every row of M is (1/K,...,1/K)
 #pragma unroll
-                    for (int r = 0; r < K; ++r) {
-                        double rs = 0.0;
+                for (int r = 0; r < K; ++r)
 #pragma unroll
-                        for (int k = 0; k < K; ++k) rs += Q[r * K + k];
+                    for (int s = 0; s < K; ++s) {
+                        double acc = 0.0;
 #pragma unroll
-                        for (int s = 0; s < K; ++s) N[r * K + s] = rs / K;
+                        for (int k = 0; k < K; ++k) acc += Q[r * K + k] * A[k][s];
+                        N[r * K + s] = acc * f[l][s];
                     }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < K; ++r)
-#pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int k = 0; k < K; ++k) acc += Q[r * K + k] * A[k][s];
-                            N[r * K + s] = acc * f[l][s];
-                        }
-                }
 #pragma unroll
                 for (int i = 0; i < KK; ++i) Q[i] = N[i];
             }
@@ -709,19 +695,13 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         for (int l = 0; l < L; ++l) {
             if (valid[l]) {
                 double nv[K], total = 0.0;
-                if (f[l][0] < 0.0) {
 #pragma unroll
-                    for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
-                    total = 1.0;
-                } else {
+                for (int s = 0; s < K; ++s) {
+                    double acc = 0.0;
 #pragma unroll
-                    for (int s = 0; s < K; ++s) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int r = 0; r < K; ++r) acc += av[r] * A[r][s];
-                        nv[s] = acc * f[l][s];
-                        total += nv[s];
-                    }
+                    for (int r = 0; r < K; ++r) acc += av[r] * A[r][s];
+                    nv[s] = acc * f[l][s];
+                    total += nv[s];
                 }
                 if (!(total > 0.0)) {
                     st |= HMCG_ST_EMIS_UNDERFLOW;

@@ -100,7 +100,7 @@ int validate(const hmcg_config* cfg)
         return HMCG_E_BADARG;
     }
     if (cfg->W < 1 || cfg->K < 2 || cfg->K > HMCG_MAXK || cfg->ldY < 2 || cfg->burnin < 0 || cfg->nrun < 0 ||
-        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0) {
+        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0 || cfg->sweep_count < 0) {
         set_err("bad hmcg_config (W=%d K=%d ldY=%d max_T=%d burnin=%d nrun=%d H=%d)", cfg->W, cfg->K, cfg->ldY,
                 cfg->max_T, cfg->burnin, cfg->nrun, cfg->H);
         return HMCG_E_BADARG;
@@ -129,9 +129,10 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H; p.nrun = cfg->nrun;
     p.sweep_begin = cfg->sweep_base;
     p.sweep_end = cfg->burnin + cfg->nrun;
+    if (cfg->sweep_count > 0 && cfg->sweep_base + cfg->sweep_count < p.sweep_end) p.sweep_end = cfg->sweep_base + cfg->sweep_count;
     p.keep_from = cfg->burnin;
     p.resume = resume ? 1 : 0;
-    p.final_launch = 1;
+    p.final_launch = (p.sweep_end == cfg->burnin + cfg->nrun) ? 1 : 0;
     for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.window_base = cfg->window_base;
     p.alpha = cfg->alpha > 0.0 ? cfg->alpha : 1.0;
@@ -234,12 +235,15 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     HIP_TRY(hipMemcpyAsync(dY.p, Y, sizeof(double) * W * ld, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(dT.p, T, sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
     if (yreal && H) { ALLOC(dyr, W * H); HIP_TRY(hipMemcpyAsync(dyr.p, yreal, sizeof(double) * W * H, hipMemcpyHostToDevice, s)); }
-    if (mu && nrun) ALLOC(dmu, W * K * nrun);
-    if (sig2 && nrun) ALLOC(dsig, W * K * nrun);
-    if (A && nrun) ALLOC(dA, W * K * K * nrun);
-    if (pi_end && nrun) ALLOC(dpe, W * K * nrun);
-    if (fcast && nrun && H) ALLOC(dfc, W * 2 * H * nrun);
-    if (summary) ALLOC(dsum, W * NS);
+    // outputs start zeroed so that skipped windows (status HMCG_ST_NONFINITE / HMCG_ST_BAD_T) read as 0
+#define ALLOC0(buf, n) do { ALLOC(buf, n); HIP_TRY(hipMemsetAsync((buf).p, 0, sizeof(double) * (size_t)(n), s)); } while (0)
+    if (mu && nrun) ALLOC0(dmu, W * K * nrun);
+    if (sig2 && nrun) ALLOC0(dsig, W * K * nrun);
+    if (A && nrun) ALLOC0(dA, W * K * K * nrun);
+    if (pi_end && nrun) ALLOC0(dpe, W * K * nrun);
+    if (fcast && nrun && H) ALLOC0(dfc, W * 2 * H * nrun);
+    if (summary) ALLOC0(dsum, W * NS);
+#undef ALLOC0
     hmcg_extras dex{};
     dex.struct_size = (int32_t)sizeof(hmcg_extras);
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;

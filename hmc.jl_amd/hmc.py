@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's `module Hmc` surface for the hot path.
+
+Julia is not available in the build image, so the tested host layer is this Python
+module; `julia/Hmc.jl` carries the same surface as a Julia module over the same C
+ABI.  Names, argument meaning and result layout follow the reference:
+
+    estopt              src/Hmc.jl:17-73     (fields and keyword defaults)
+    makey/startdate/enddate/yobs/yend   src/Hmc.jl:85-107
+    makedate            src/Hmc.jl:573-582
+    estimatemodel       src/Hmc.jl:850-865   -> (mu, sigma, pib, A, forecasts, obsdates)
+    forecast            src/Hmc.jl:658-667
+    saveresults/basicsave   src/Hmc.jl:707-748   (five per-window CSVs)
+    runaggregate layout src/Hmc.jl:1025-1078 (`*_summary.csv`)
+
+New (the reference batches by launching one SLURM task per window,
+slurmscripts/base_estimation.sh:5): `estimatewindows`, one call for many windows.
+
+All sampling runs in libhmcgibbs (HIP, gfx950).  No CPU fallback.
+"""
+import datetime as _dt
+import os
+import numpy as np
+
+from . import _lib
+
+class Samples:
+    """The NamedTuple estimatemodel returns upstream (src/Hmc.jl:864): fields μ, σ, πb, A,
+    forecasts, obsdates (ASCII aliases mu, sigma, pib), plus the window's status word."""
+
+    def __init__(self, μ, σ, πb, A, forecasts, obsdates, status=0):
+        self.μ, self.σ, self.πb, self.A = μ, σ, πb, A
+        self.forecasts, self.obsdates, self.status = forecasts, obsdates, status
+
+    mu = property(lambda s: s.μ)
+    sigma = property(lambda s: s.σ)
+    pib = property(lambda s: s.πb)
+
+
+def makedate(x):
+    """Stata monthly date (months since 1960-01) -> date (src/Hmc.jl:573-582)."""
+    y = int(x)
+    return _dt.date(y // 12 + 1960, y % 12 + 1, 1)
+
+
+class estopt:
+    """Run options; field names and defaults of the reference struct (src/Hmc.jl:17-60).
+
+    Index ranges are 1-based inclusive `range` objects or sequences, as in Julia
+    (sampleRange=range(1, 122) is Julia's 1:121).  As in the reference, windows are
+    expected to start at index 1."""
+
+    def __init__(self, rawdata, dates, sampleRange=range(1, 122), signalRange=range(2, 2), signalSave=range(2, 2),
+                 endIndex=121, horizons=(12,), D=3, burnin=1000, Nrun=1000, signalburnin=1000, signalNrun=1000,
+                 noise=0.0, noiseSamples=1, σsignal=0.0, series="offical", seed=1234):
+        self.rawdata = np.asarray(rawdata, dtype=np.float64)
+        self.dates = list(dates)
+        self.sampleRange = list(sampleRange)
+        self.signalRange = list(signalRange)
+        self.signalSave = list(signalSave)
+        if not set(self.signalRange) <= set(self.sampleRange):
+            print("ERROR: signalRange is not a subset of sampleRange")     # @error only logs (src/Hmc.jl:61)
+        if not set(self.signalSave) <= set(self.signalRange):
+            print("ERROR: signalSave is not a subset of signalRange")      # src/Hmc.jl:62
+        self.endIndex = int(endIndex)
+        self.horizons = list(horizons)
+        self.D = int(D)
+        self.burnin = int(burnin)
+        self.Nrun = int(Nrun)
+        self.signalburnin = int(signalburnin)
+        self.signalNrun = int(signalNrun)
+        self.noise = float(noise)
+        self.noiseSamples = int(noiseSamples)
+        self.σsignal = float(σsignal)
+        self.series = series
+        self.seed = int(seed)
+        update_itators(self)
+
+
+def update_itators(opt):
+    """src/Hmc.jl:75-83 (the reference's spelling is kept)."""
+    sig = set(opt.signalRange)
+    opt.obsRange = [i for i in opt.sampleRange if i not in sig]
+
+
+def makey(opt):
+    return opt.rawdata[np.asarray(opt.sampleRange, dtype=np.int64) - 1]
+
+
+def enddate(opt, extra=0):
+    return opt.dates[opt.endIndex + extra - 1]
+
+
+def startdate(opt):
+    return opt.dates[opt.sampleRange[0] - 1]
+
+
+def yobs(opt, index):
+    return opt.rawdata[index - 1]
+
+
+def yend(opt, extra=0):
+    return opt.rawdata[opt.endIndex + extra - 1]
+
+
+def forecast(μ, A, πb, horizon, Yreal):
+    """(pi' A^h) . mu and its error (src/Hmc.jl:658-667).  Host arithmetic on one draw,
+    kept for API parity; per-draw forecasts inside estimatemodel come from the GPU."""
+    S1 = np.asarray(πb, dtype=np.float64) @ np.linalg.matrix_power(np.asarray(A, dtype=np.float64), int(horizon))
+    f = float(S1 @ np.asarray(μ, dtype=np.float64))
+    return f, f - Yreal
+
+
+def _yreal_row(rawdata, endIndex, horizons):
+    out = np.full(len(horizons), np.nan)
+    for i, h in enumerate(horizons):
+        j = endIndex + h
+        if 1 <= j <= len(rawdata):
+            out[i] = rawdata[j - 1]
+    return out
+
+
+def _check_live_path(opt):
+    if len(opt.signalRange) != 0:
+        raise NotImplementedError("signal ranges (estimatesignals!) are outside the accelerated path (SURVEY.md 8f)")
+    if opt.sampleRange[0] != 1 or opt.sampleRange != list(range(1, opt.sampleRange[-1] + 1)):
+        raise ValueError("sampleRange must be 1:N (the reference indexes window-relative arrays with absolute "
+                         "indices, src/Hmc.jl:254,406 -- only windows starting at 1 are meaningful)")
+
+
+def _unpack(res, w, nrun, K, H, obsdate):
+    mu = res["mu"][w].T.copy()                       # (nrun, K)
+    sig = res["sig2"][w].T.copy()
+    pe = res["pi_end"][w].T.copy()
+    A = np.transpose(res["A"][w], (2, 1, 0)).copy()  # [d, i, j]
+    fc = res["fcast"][w].T.copy() if H else np.zeros((nrun, 0))
+    return Samples(mu, sig, pe[:, None, :], A, fc, [obsdate] * nrun, int(res["status"][w]))
+
+
+def estimatemodel(opt, device=0):
+    """Hmc.estimatemodel(opt) (src/Hmc.jl:850-865) on the GPU.
+
+    Returns Samples(μ[Nrun,D], σ[Nrun,D] (variances), πb[Nrun,1,D], A[Nrun,D,D],
+    forecasts[Nrun,2H], obsdates).  πb keeps only the window's last time step -- the
+    only slice the reference's outputs consume (`samples.πb[:,end,:]`, src/Hmc.jl:744,861)
+    -- so `samples.πb[:, -1, :]` reads exactly as upstream."""
+    _check_live_path(opt)
+    Y = makey(opt)
+    res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.burnin, opt.Nrun, tuple(opt.horizons),
+                                   _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
+                                   device=device)
+    return _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
+
+
+class BatchResult:
+    """Result of estimatewindows: per-window posterior summaries (+ optional draws)."""
+
+    def __init__(self, opts, res, keep_draws):
+        self.opts = opts
+        self.summary = res["summary"]          # (W, 3K+K^2+2H)
+        self.status = res["status"]
+        self.kernel_ms = res.get("kernel_ms")
+        self._res = res if keep_draws else None
+
+    def samples(self, w):
+        if self._res is None:
+            raise ValueError("draws were not kept (keep_draws=False)")
+        o = self.opts[w]
+        return _unpack(self._res, w, o.Nrun, o.D, len(o.horizons), enddate(o))
+
+
+def estimatewindows(rawdata, dates, endIndices, startIndex=1, keep_draws=False, device=0, window_ids=None, **kwargs):
+    """Batched estimatemodel over many expanding windows (one GPU call).
+
+    Window w uses sampleRange = startIndex:endIndices[w], endIndex = endIndices[w]; the
+    remaining keyword arguments are estopt's.  RNG stream ids default to the position
+    in `endIndices`; pass window_ids to pin them (sharded runs)."""
+    if startIndex != 1:
+        raise ValueError("windows must start at index 1 (see estopt)")
+    rawdata = np.asarray(rawdata, dtype=np.float64)
+    opts = [estopt(rawdata, dates, sampleRange=range(1, int(e) + 1), endIndex=int(e), **kwargs) for e in endIndices]
+    o0 = opts[0]
+    W = len(opts)
+    Tw = np.array([len(o.sampleRange) for o in opts], dtype=np.int32)
+    ld = int(Tw.max())
+    Y = np.zeros((W, ld))
+    yreal = np.zeros((W, len(o0.horizons)))
+    for w, o in enumerate(opts):
+        Y[w, :Tw[w]] = makey(o)
+        yreal[w] = _yreal_row(rawdata, o.endIndex, o.horizons)
+    res = _lib.estimate_batch_host(Y, Tw, o0.D, o0.burnin, o0.Nrun, tuple(o0.horizons), yreal, seed=o0.seed,
+                                   device=device, want_draws=keep_draws, window_ids=window_ids)
+    return BatchResult(opts, res, keep_draws)
+
+
+# ----------------------------------------------------------------- CSV output --
+
+def _fmt(x):
+    """Float text in the style of the reference's committed CSVs (CSV.jl 0.5.16):
+    shortest round-trip digits; integral values without a fraction; |x| < 1e-4 as
+    <integer mantissa>e-<n> (e.g. 24e-11)."""
+    x = float(x)
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "Inf" if x > 0 else "-Inf"
+    if x == int(x) and abs(x) < 1e15:
+        return str(int(x))
+    r = repr(x)
+    if abs(x) < 1e-4:
+        mant, exp = ("%r" % x).split("e") if "e" in r else (None, None)
+        if mant is None:                       # repr chose positional notation (1e-4 > |x| >= 1e-5 never does)
+            return r
+        sign = "-" if mant.startswith("-") else ""
+        mant = mant.lstrip("-")
+        ip, _, fp = mant.partition(".")
+        digits = (ip + fp).lstrip("0") or "0"
+        e10 = int(exp) - len(fp)
+        return "%s%se%d" % (sign, digits, e10)
+    return r
+
+
+def _header(opt, nfc):
+    D = opt.D
+    h1 = ["state_%d" % i for i in range(1, D + 1)]
+    h2 = ["trans_%d_%d" % (i, j) for j in range(1, D + 1) for i in range(1, D + 1)]   # vec of [i,j] column-major (src/Hmc.jl:727)
+    h3 = []
+    for h in opt.horizons:
+        h3 += ["forecast_%d" % h, "forecast_error_%d" % h]
+    return h1, h2, h3[:nfc]
+
+
+def basicsave(data, dates, fname, dataheader, precision=5):
+    """src/Hmc.jl:707-722 without signals: round to `precision` digits, date first."""
+    data = np.asarray(data, dtype=np.float64)
+    sc = 10.0 ** precision
+    rounded = np.rint(data * sc) / sc
+    with open(fname, "w") as f:
+        f.write(",".join(["date"] + list(dataheader)) + "\n")
+        for d, row in zip(dates, rounded):
+            f.write(",".join([str(d)] + [_fmt(v) for v in row]) + "\n")
+
+
+def saveresults(samples, opt, dir, hassignals=False):
+    """Five per-window CSVs with the reference's names and columns (src/Hmc.jl:724-748).
+    The reference ignores `dir` when hassignals=false and writes to
+    data/output/<series>/ -- which is what its only caller passes (code/run_hmm.jl:116,120)."""
+    if hassignals:
+        raise NotImplementedError("signal outputs are outside the accelerated path (SURVEY.md 8f)")
+    os.makedirs(dir, exist_ok=True)
+    h1, h2, h3 = _header(opt, samples.forecasts.shape[1])
+    ed = enddate(opt)
+    n = samples.μ.shape[0]
+    basicsave(samples.μ, samples.obsdates, os.path.join(dir, "filtered_means_%s.csv" % ed), h1)
+    basicsave(samples.σ, samples.obsdates, os.path.join(dir, "filtered_variances_%s.csv" % ed), h1)
+    basicsave(samples.πb[:, -1, :], samples.obsdates, os.path.join(dir, "filtered_state_probs_%s.csv" % ed), h1)
+    basicsave(samples.A.reshape(n, -1, order="F"), samples.obsdates,
+              os.path.join(dir, "filtered_trans_probs_%s.csv" % ed), h2)
+    basicsave(samples.forecasts, samples.obsdates, os.path.join(dir, "forecasts_%s.csv" % ed), h3)
+
+
+SUMMARY_FILES = ("filtered_means", "filtered_variances", "filtered_state_probs", "filtered_trans_probs", "forecasts")
+
+
+def write_summaries(summary, opts, dir, legacy_trans_header=False):
+    """`*_summary.csv` files in runaggregate's layout (src/Hmc.jl:1025-1078): header
+    `date,<col>_mean,...`, one row per end date in ascending date order.  `summary` is the
+    (W, 3K+K^2+2H) block of on-device means of the 5-digit-rounded draws.
+    legacy_trans_header reproduces the committed fixtures' trans_<j>_<i> naming
+    (code/deprecated/Hmc.jl_08072019bak:711)."""
+    os.makedirs(dir, exist_ok=True)
+    o0 = opts[0]
+    K, H = o0.D, len(o0.horizons)
+    h1, h2, h3 = _header(o0, 2 * H)
+    if legacy_trans_header:
+        h2 = ["trans_%d_%d" % (j, i) for j in range(1, K + 1) for i in range(1, K + 1)]
+    cols = [(0, K, h1), (K, 2 * K, h1), (2 * K, 3 * K, h1), (3 * K, 3 * K + K * K, h2),
+            (3 * K + K * K, 3 * K + K * K + 2 * H, h3)]
+    order = sorted(range(len(opts)), key=lambda w: enddate(opts[w]))
+    paths = []
+    for name, (a, b, hdr) in zip(SUMMARY_FILES, cols):
+        p = os.path.join(dir, name + "_summary.csv")
+        with open(p, "w") as f:
+            f.write(",".join(["date"] + [h + "_mean" for h in hdr]) + "\n")
+            for w in order:
+                f.write(",".join([str(enddate(opts[w]))] + [_fmt(v) for v in summary[w, a:b]]) + "\n")
+        paths.append(p)
+    return paths

@@ -63,7 +63,8 @@ extern "C" {
 
 /* status[w] bits */
 #define HMCG_ST_BAD_INVGAMMA   1 /* a<=0 or b<=0 in the InvGamma update: old variance kept (src/Hmc.jl:319-329) */
-#define HMCG_ST_EMIS_UNDERFLOW 2 /* all K emission pdfs underflowed (or zero normaliser) at some step: uniform step substituted (reference would throw, src/Hmc.jl:435) */
+#define HMCG_ST_EMIS_UNDERFLOW 2 /* all K emission pdfs underflowed at some step: that observation was treated as missing (f=1); or a zero
+                                    normaliser was replaced by the uniform law (reference would produce NaN and throw, src/Hmc.jl:435) */
 #define HMCG_ST_NONFINITE      4 /* non-finite observation: window skipped, outputs untouched */
 #define HMCG_ST_GAMMA_CAP      8 /* gamma rejection sampler hit its attempt cap */
 #define HMCG_ST_BAD_T         16 /* T[w] < 2 or T[w] > max_T: window skipped */
@@ -88,7 +89,8 @@ typedef struct hmcg_config {
     int32_t flags;           /* HMCG_FLAG_* */
     int32_t threads_per_window; /* 0 = auto (256); 128/256/512 */
     int32_t sweep_base;      /* global index of the first sweep of this call (0 unless resuming) */
-    int32_t reserved0;
+    int32_t sweep_count;     /* sweeps to run in this call; 0 = all remaining (burnin+nrun-sweep_base).  A call that
+                                stops short writes extras.xstate/sumacc so a later RESUME call can continue */
     double alpha;            /* InvGamma prior sample size, 0 -> 1.0 (HyperParams(Y,D), src/Hmc.jl:137) */
     double nu;               /* Normal prior sample size,   0 -> 1.0 (src/Hmc.jl:140) */
 } hmcg_config;
@@ -123,7 +125,8 @@ const char* hmcg_last_error(void);    /* thread-local, never NULL */
 void hmcg_shutdown(void);             /* releases the library's streams/workspaces */
 
 /* Host-buffer entry: copies Y/T/yreal to the device, runs, copies results back.
- * Any output pointer may be NULL (that output is not produced). */
+ * Any output pointer may be NULL (that output is not produced).  Outputs of skipped windows
+ * (status HMCG_ST_NONFINITE / HMCG_ST_BAD_T) are zero here; the device entry leaves them untouched. */
 int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* T, const double* yreal,
                         double* mu, double* sig2, double* A, double* pi_end, double* fcast,
                         double* summary, int32_t* status, const hmcg_extras* extras, hmcg_timing* timing);

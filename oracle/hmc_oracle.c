@@ -52,7 +52,7 @@
 
 /* status bits (same meaning as include/hmcg.h) */
 #define ST_BAD_INVGAMMA 1   /* a<=0 or b<=0: old sigma kept (src/Hmc.jl:319-329) */
-#define ST_EMIS_UNDERFLOW 2 /* all K emission pdfs < 1e-300 at some t: uniform step */
+#define ST_EMIS_UNDERFLOW 2 /* all K emission pdfs < 1e-300 at some t: observation treated as missing */
 #define ST_NONFINITE 4      /* non-finite input */
 #define ST_GAMMA_CAP 8      /* gamma rejection loop hit its attempt cap */
 
@@ -239,11 +239,18 @@ static void chain_init(chain_t *c, const int *x_init)
     if (K > 1) c->mu[K - 1] = hi;
     for (int t = 0; t < T; ++t) {                           /* :185-187 */
         if (x_init) { c->X[t] = x_init[t]; continue; }
+        /* findmax(pdf.(Normal.(mu, sigma), Y[t]))[2] with every sigma equal (= std(Y), used as an sd
+         * here): the largest pdf belongs to the nearest initial mean, first index on ties.  We compare
+         * distances rather than pdf values: the two agree except where libm's exp rounds two
+         * different arguments to the same double, and that sub-ulp case is structural, not rare --
+         * for even K and odd T the median observation sits exactly midway between the two middle
+         * means -- so a rule that does not depend on the exp implementation is needed for the
+         * GPU path and this oracle to start from the same X. */
         int best = 0;
-        double bv = normpdf(c->mu[0], c->sig2[0], Y[t]);    /* sigma slot used as an sd here */
+        double bd = fabs(Y[t] - c->mu[0]);
         for (int k = 1; k < K; ++k) {
-            double v = normpdf(c->mu[k], c->sig2[k], Y[t]);
-            if (v > bv) { bv = v; best = k; }               /* findmax: first max wins */
+            double d = fabs(Y[t] - c->mu[k]);
+            if (d < bd) { bd = d; best = k; }
         }
         c->X[t] = best;
     }
@@ -333,8 +340,8 @@ static void update_A(chain_t *c, const rng_t *g)
 
 /* forwardupdate_P (src/Hmc.jl:371-440).  Direct-probability domain, per-step
  * renormalisation, s-outer / r-inner accumulation.  Extension (reference would
- * produce NaN and throw): if every emission pdf at step t is < 1e-300 the step is
- * replaced by the uniform law and ST_EMIS_UNDERFLOW is raised. */
+ * produce NaN and throw): if every emission pdf at step t is < 1e-300 the
+ * observation is treated as missing (f = 1) and ST_EMIS_UNDERFLOW is raised. */
 static void forward_update(chain_t *c)
 {
     const int K = c->K, T = c->T;
@@ -351,9 +358,10 @@ static void forward_update(chain_t *c)
         }
         for (int s = 0; s < K; ++s) if (f[s] > fmax) fmax = f[s];
         if (!(fmax >= 1e-300)) {
+            /* every pdf underflowed: the observation carries no usable likelihood; it is treated as
+             * missing (f = 1: the step becomes the prediction pi[t-1,:]*A) and the window is flagged */
             c->status |= ST_EMIS_UNDERFLOW;
-            for (int s = 0; s < K; ++s) { for (int r = 0; r < K; ++r) PF(c, t, r, s) = 1.0 / (K * K); PIF(c, t, s) = 1.0 / K; }
-            continue;
+            for (int s = 0; s < K; ++s) f[s] = 1.0;
         }
         double total = 0.0;
         for (int s = 0; s < K; ++s)

@@ -1,0 +1,235 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle on the
+same seeded inputs.  Bar: state paths (integers) bit-exact; floating-point draws, filtered
+probabilities and summaries within 1e-9 relative-to-(1+|x|) -- BASELINE.json's north_star
+tolerance ("filtered state probabilities within 1e-9 of reference"); observed ~1e-14.
+The GPU path is a time-parallel scan, the oracle is sequential, so bitwise float equality is
+not expected; a categorical draw can only flip when a uniform lands within ~1e-14 of a CDF
+boundary, which these fixed seeds do not do."""
+import numpy as np
+import pytest
+
+from hmc_jl_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+FLOAT_KEYS = ("mu", "sig2", "A", "pi_end", "fcast", "summary", "pif_final")
+
+
+def close(g, o, tol=TOL):
+    return float(np.max(np.abs(g - o) / (1.0 + np.abs(o)))) if g.size else 0.0
+
+
+def check_against_oracle(oracle, Y, Tw, K, burnin, nrun, horizons=(12,), yreal=None, window_ids=None, seed=1234, **kw):
+    g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, horizons, yreal, seed=seed, want_state=True,
+                                 window_ids=window_ids, **kw)
+    W = Y.shape[0]
+    for w in range(W):
+        wid = w if window_ids is None else int(window_ids[w])
+        o = oracle.estimate_window(Y[w, :Tw[w]], K, burnin, nrun, horizons, None if yreal is None else yreal[w],
+                                   seed=seed, window_id=wid)
+        assert g["status"][w] == o["status"], (w, g["status"][w], o["status"])
+        assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"]), "state path differs in window %d" % w
+        assert close(g["mu"][w].T, o["mu"]) < TOL
+        assert close(g["sig2"][w].T, o["sig2"]) < TOL
+        assert close(np.transpose(g["A"][w], (2, 1, 0)), o["A"]) < TOL
+        assert close(g["pi_end"][w].T, o["pi_end"]) < TOL
+        if len(horizons):
+            assert close(g["fcast"][w].T, o["fcast"]) < TOL or yreal is None
+            assert close(g["fcast"][w, 0::2].T, o["fcast"][:, 0::2]) < TOL
+        s_ok = ~np.isnan(o["summary"])
+        assert close(g["summary"][w][s_ok], o["summary"][s_ok]) < TOL
+        assert close(g["pif_final"][w, :Tw[w]], o["pif_final"]) < TOL
+    return g
+
+
+def test_cfg1_plumbing_case(hmclib, oracle):
+    """BASELINE configs[0]: 3-state, T=200, 1 window, 100 draws."""
+    Y, Tw, fut = synth.generate_panel(1, 200, 3)
+    check_against_oracle(oracle, Y, Tw, 3, 0, 100, (12,), fut[:, 11:12])
+
+
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_ragged_windows_all_chunkings(hmclib, oracle, K):
+    """Ragged panel crossing every steps-per-thread variant boundary (L=1,2,4,8 at 256 threads)
+    and the wave boundaries (63/64/65, 255/256/257)."""
+    lens = [2, 3, 5, 63, 64, 65, 200, 255, 256, 257, 511, 513, 1000, 1024, 1025, 2047]
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
+    for sub in ([0, 1, 2, 3, 4, 5, 6, 7, 8], [9, 10], [11, 12, 13], [14, 15]):
+        idx = np.array(sub)
+        ld = int(Tw[idx].max())
+        check_against_oracle(oracle, np.ascontiguousarray(Y[idx, :ld]), Tw[idx], K, 3, 12, (12,), fut[idx, 11:12],
+                             window_ids=idx)
+
+
+def test_mixed_lengths_in_one_call(hmclib, oracle):
+    lens = [1000, 17, 400, 2]
+    Y, Tw, fut = synth.generate_panel(4, 1000, 3, ragged=lens)
+    check_against_oracle(oracle, Y, Tw, 3, 2, 10, (1, 12), fut[:, [0, 11]])
+
+
+def test_teacher_forced_single_sweep(hmclib, oracle):
+    """Given the same X, one sweep: parameter draws, the whole filtered-probability path and the
+    redrawn states must agree (this isolates the deterministic kernels from chain history)."""
+    rng = np.random.default_rng(11)
+    W, T, K = 6, 1000, 3
+    Y, Tw, _ = synth.generate_panel(W, T, K)
+    X0 = rng.integers(0, K, size=(W, T)).astype(np.int32)
+    g = _lib.estimate_batch_host(Y, Tw, K, 0, 1, (), None, x_init=X0, want_state=True)
+    for w in range(W):
+        o = oracle.estimate_window(Y[w], K, 0, 1, (), None, window_id=w, x_init=X0[w])
+        assert np.array_equal(g["x_final"][w], o["x_final"])
+        assert np.max(np.abs(g["pif_final"][w] - o["pif_final"])) < TOL
+        assert close(g["mu"][w].T, o["mu"]) < TOL and close(np.transpose(g["A"][w], (2, 1, 0)), o["A"]) < TOL
+
+
+def test_real_data_expanding_windows(hmclib, oracle, inflation):
+    y, _ = inflation
+    ends = [120, 121, 250, 579]
+    ld = max(ends)
+    Y = np.zeros((len(ends), ld)); Tw = np.array(ends, dtype=np.int32)
+    yreal = np.full((len(ends), 1), np.nan)
+    for i, e in enumerate(ends):
+        Y[i, :e] = y[:e]
+        if e + 12 <= len(y):
+            yreal[i, 0] = y[e + 11]
+    check_against_oracle(oracle, Y, Tw, 3, 20, 60, (12,), yreal)
+
+
+def test_status_flags(hmclib, oracle):
+    Y, Tw, _ = synth.generate_panel(3, 300, 3)
+    Y[1, 10] = np.nan                       # non-finite input
+    Tw[2] = 1                               # too short
+    g = _lib.estimate_batch_host(Y, Tw, 3, 2, 5, (12,), None, want_state=True)
+    assert g["status"][0] == 0
+    assert g["status"][1] == _lib.ST_NONFINITE
+    assert g["status"][2] == _lib.ST_BAD_T
+    assert (g["mu"][1:] == 0).all()                      # skipped windows leave their outputs untouched
+    # Emission underflow (the reference would produce NaN and throw, src/Hmc.jl:435): teacher-force every
+    # point, including one 1e6 outlier, into state 0 of a long window.  sd_0 ~ 1e6/sqrt(T) puts the outlier
+    # 55 sd out, the empty states' prior draws put it ~1e6 sd out: all K pdfs underflow at that step.
+    T = 3000
+    Yu, _, _ = synth.generate_panel(1, T, 3)
+    Yu[0, 1500] = 1e6
+    x0 = np.zeros((1, T), dtype=np.int32)
+    gu = _lib.estimate_batch_host(Yu, [T], 3, 0, 1, (12,), None, x_init=x0, want_state=True)
+    o = oracle.estimate_window(Yu[0], 3, 0, 1, (12,), None, x_init=x0[0])
+    assert o["status"] & 2 and gu["status"][0] & _lib.ST_EMIS_UNDERFLOW
+    assert np.array_equal(gu["x_final"][0], o["x_final"])
+    assert close(gu["mu"][0].T, o["mu"]) < TOL and close(gu["pif_final"][0], o["pif_final"]) < TOL
+    assert np.isfinite(gu["mu"][0]).all() and np.isfinite(gu["pif_final"][0]).all()
+    with pytest.raises(_lib.HmcgError, match="no kernel"):
+        _lib.estimate_batch_host(np.zeros((1, 20000)), [20000], 3, 1, 1)
+    with pytest.raises(_lib.HmcgError):
+        _lib.estimate_batch_host(np.zeros((1, 100)), [100], 9, 1, 1)
+
+
+def test_sharding_reproduces_unsharded_rows(hmclib):
+    """Explicit RNG stream ids: any subset of windows, in any order, on its own call equals the
+    same rows of the full run bit for bit (what makes the multi-GPU split invisible)."""
+    Y, Tw, fut = synth.generate_panel(12, 500, 3)
+    full = _lib.estimate_batch_host(Y, Tw, 3, 5, 30, (12,), fut[:, 11:12], want_state=True)
+    ids = np.array([7, 2, 11])
+    part = _lib.estimate_batch_host(Y[ids], Tw[ids], 3, 5, 30, (12,), fut[ids, 11:12], want_state=True, window_ids=ids)
+    for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "x_final", "pif_final"):
+        assert np.array_equal(part[k], full[k][ids]), k
+    based = _lib.estimate_batch_host(Y[4:8], Tw[4:8], 3, 5, 30, (12,), fut[4:8, 11:12], window_base=4)
+    assert np.array_equal(based["mu"], full["mu"][4:8])
+
+
+def test_checkpoint_resume_is_exact(hmclib):
+    """12+28 sweeps in one call == 15 sweeps, checkpoint (xstate, sumacc, status), resume 25."""
+    Y, Tw, fut = synth.generate_panel(5, 700, 3)
+    one = _lib.estimate_batch_host(Y, Tw, 3, 12, 28, (12,), fut[:, 11:12], want_state=True)
+    a = _lib.estimate_batch_host(Y, Tw, 3, 12, 28, (12,), fut[:, 11:12], want_state=True, sweep_count=15)
+    b = _lib.estimate_batch_host(Y, Tw, 3, 12, 28, (12,), fut[:, 11:12], resume_state=a, sweep_base=15)
+    assert np.array_equal(a["mu"][:, :, :3], one["mu"][:, :, :3])          # draws 0..2 came from the first call
+    assert np.array_equal(b["mu"][:, :, 3:], one["mu"][:, :, 3:])          # the rest from the resumed one
+    assert np.array_equal(b["A"][..., 3:], one["A"][..., 3:])
+    assert np.array_equal(b["summary"], one["summary"])
+    assert np.array_equal(b["xstate"][:, :700], one["x_final"].astype(np.uint8))
+
+
+def test_threads_per_window_variants_agree(hmclib, oracle):
+    """The 128- and 512-thread decompositions scan in a different association order; they must
+    still match the oracle (and hence each other) within tolerance with identical state paths."""
+    Y, Tw, fut = synth.generate_panel(3, 1000, 3)
+    for tpw in (128, 512):
+        check_against_oracle(oracle, Y, Tw, 3, 2, 20, (12,), fut[:, 11:12], threads_per_window=tpw)
+
+
+def test_full_size_cfg2_properties_and_subset_parity(hmclib, oracle):
+    """BASELINE configs[1] at full size (256 windows, T=1000, 1000 draws): size-independent
+    properties on everything, oracle parity on a subset of windows at full length."""
+    W, T, K, n = 256, 1000, 3, 1000
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    yreal = fut[:, 11:12]
+    g = _lib.estimate_batch_host(Y, Tw, K, 0, n, (12,), yreal, want_state=True)
+    assert (g["status"] == 0).all()
+    mu = np.transpose(g["mu"], (0, 2, 1)); A = np.transpose(g["A"], (0, 3, 2, 1)); pe = np.transpose(g["pi_end"], (0, 2, 1))
+    assert (np.diff(mu, axis=2) > 0).all()                                     # labels sorted on every draw
+    assert np.max(np.abs(A.sum(axis=3) - 1)) < 1e-12 and (A > 0).all()         # row-stochastic
+    assert np.max(np.abs(pe.sum(axis=2) - 1)) < 1e-12
+    assert (g["sig2"] > 0).all() and np.isfinite(g["fcast"]).all()
+    assert np.max(np.abs(g["pif_final"].sum(axis=2) - 1)) < 1e-12              # every filtered law is a simplex point
+    assert g["x_final"].min() >= 0 and g["x_final"].max() < K
+    # forecast identity and error column, recomputed on the host from the returned draws
+    A12 = np.linalg.matrix_power(A[:8], 12)
+    f = np.einsum("wdr,wdrs,wds->wd", pe[:8], A12, mu[:8])
+    assert np.max(np.abs(f - g["fcast"][:8, 0, :])) < 1e-9
+    assert np.max(np.abs(g["fcast"][:, 1, :] - (g["fcast"][:, 0, :] - yreal))) < 1e-12
+    # summary = mean over draws of round(x, 5) in the documented row order
+    rows = np.concatenate([g["mu"], g["sig2"], g["pi_end"], g["A"].reshape(W, K * K, n), g["fcast"]], axis=1)
+    ref = (np.rint(rows * 1e5) / 1e5).mean(axis=2)
+    assert np.max(np.abs(ref - g["summary"])) < 1e-10
+    # determinism: a second run is bitwise identical
+    g2 = _lib.estimate_batch_host(Y, Tw, K, 0, n, (12,), yreal, want_state=True)
+    for k in FLOAT_KEYS + ("x_final",):
+        assert np.array_equal(g[k], g2[k]), k
+    # oracle parity on 6 windows at full size
+    ids = np.array([0, 1, 37, 128, 200, 255])
+    for w in ids:
+        o = oracle.estimate_window(Y[w], K, 0, n, (12,), yreal[w], window_id=int(w))
+        assert np.array_equal(g["x_final"][w], o["x_final"])
+        assert close(g["mu"][w].T, o["mu"]) < TOL and close(g["sig2"][w].T, o["sig2"]) < TOL
+        assert close(np.transpose(g["A"][w], (2, 1, 0)), o["A"]) < TOL and close(g["fcast"][w].T, o["fcast"]) < TOL
+        assert close(g["summary"][w], o["summary"]) < TOL and close(g["pif_final"][w], o["pif_final"]) < TOL
+
+
+def test_device_resident_entry_matches_host_entry(hmclib):
+    from hmc_jl_amd.device import DevicePanel
+    Y, Tw, fut = synth.generate_panel(16, 600, 3)
+    host = _lib.estimate_batch_host(Y, Tw, 3, 4, 25, (12,), fut[:, 11:12])
+    p = DevicePanel(Y, Tw, 3, 25, (12,), fut[:, 11:12])
+    ms = p.run(burnin=4)
+    assert ms > 0
+    for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary"):
+        assert np.array_equal(getattr(p, k).cpu().numpy(), host[k]), k
+    assert (p.status.cpu().numpy() == 0).all()
+    p.run(burnin=4, timed=False)            # asynchronous form
+    p.sync()
+    assert np.array_equal(p.summary.cpu().numpy(), host["summary"])
+
+
+@pytest.mark.parametrize("idx,date", [(120, "1979-12-01"), (350, "1999-02-01"), (579, "2018-03-01")])
+def test_gpu_posterior_vs_reference_committed_summaries(hmclib, inflation, golden_summaries, idx, date):
+    """Statistical agreement of the GPU chain with the reference's own committed outputs
+    (data/output/official/*_summary.csv: 100k burn-in + 250k draws upstream; here 10k + 100k)."""
+    y, _ = inflation
+    yreal = np.array([[y[idx + 11]]]) if idx + 12 <= len(y) else None
+    g = _lib.estimate_batch_host(y[None, :idx], [idx], 3, 10000, 100000, (12,), yreal, want_draws=False)
+    s = g["summary"][0]
+    K = 3
+    assert g["status"][0] == 0
+    np.testing.assert_allclose(s[0:K], golden_summaries["filtered_means"][1][date], atol=0.04)
+    np.testing.assert_allclose(s[K:2 * K], golden_summaries["filtered_variances"][1][date], atol=0.08, rtol=0.02)
+    np.testing.assert_allclose(s[2 * K:3 * K], golden_summaries["filtered_state_probs"][1][date], atol=0.002)
+    np.testing.assert_allclose(s[3 * K:3 * K + K * K], golden_summaries["filtered_trans_probs"][1][date], atol=0.003)
+    np.testing.assert_allclose(s[3 * K + K * K], golden_summaries["forecasts"][1][date][0], atol=0.03)
+
+
+def test_gpu_reference_unit_test_truth_recovery(hmclib):
+    """test/runtests.jl:20-57 on the GPU path: 2-state, 476 of 500 points, 3000 + 1000 sweeps."""
+    Y, _ = synth.generate_window(500, 2, seed=126)
+    g = _lib.estimate_batch_host(Y[None, :476], [476], 2, 3000, 1000, (12,), np.array([[Y[487]]]))
+    np.testing.assert_allclose(g["mu"][0].mean(axis=1), [-5.0, 4.0], atol=0.3)
+    np.testing.assert_allclose(g["sig2"][0].mean(axis=1), [1.0, 0.5], atol=0.5)
