@@ -32,12 +32,29 @@ def algorithmic_bytes_per_draw(T_, K_, H_):
     return T_ * (8 + 16 * K_ + 2) + 8 * (3 * K_ + K_ * K_ + 2 * H_)
 
 
+def usable_cores(omp_max):
+    """Threads this process may actually run at once: min(OpenMP's view, the affinity mask,
+    the cgroup CPU quota) -- the GPU box exposes every host core but caps the job's share."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(Y, Tw, yreal):
     """The oracle (kind "port": C restatement of the reference's CPU path) timed on the
     host cores over a bounded sample of the same workload: 2 windows per core, draws per
     window sized from a calibration run to ~8 s of wall time."""
     from oracle import oracle
-    cores = oracle.max_threads()
+    cores = usable_cores(oracle.max_threads())
     nwin = min(2 * cores, Y.shape[0])
     t0 = time.perf_counter()
     oracle.estimate_batch(Y[:1], Tw[:1], K, 0, 200, (HORIZON,), yreal[:1], nthreads=1)
