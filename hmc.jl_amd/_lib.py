@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libhmcgibbs.so")
+SO_PATH = os.path.join(CSRC, os.environ.get("HMCG_LIB", "libhmcgibbs.so"))   # HMCG_LIB: diagnostic builds only
 
 HMCG_MAXH = 8
 HMCG_MAXK = 8
@@ -168,7 +168,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         out["x_final"] = np.zeros((W, ldY), dtype=np.int32)
         out["pif_final"] = np.zeros((W, ldY, K))
         out["xstate"] = np.zeros((W, ldY), dtype=np.uint8)
-        out["sumacc"] = np.zeros((W, NS))
+        out["sumacc"] = np.zeros((W, NS + K))
         ex.x_final = out["x_final"].ctypes.data
         ex.pif_final = out["pif_final"].ctypes.data
         ex.xstate = out["xstate"].ctypes.data

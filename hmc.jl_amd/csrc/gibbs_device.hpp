@@ -10,14 +10,21 @@
 //
 // Parallel decomposition (not in the reference, which is sequential in t):
 //   * thread j owns the L consecutive time steps t = j*L .. j*L+L-1;
-//   * forward filter  = prefix scan of the (scaled) K x K matrices A*diag(f_t):
-//     per-thread product of L matrices, Kogge-Stone scan over the 64 lanes of a
-//     wave, wave totals through LDS, then a per-thread replay of the normalised
-//     recursion from the scanned prefix vector;
+//   * forward filter  = prefix scan of the (power-of-two scaled) K x K matrices
+//     A*diag(f_t): per-thread product of L matrices, a DPP scan over the 64 lanes of a
+//     wave (row_shr 1/2/4/8, row_bcast 15/31), wave totals through LDS, then a
+//     per-thread replay of the normalised recursion from the scanned prefix vector;
 //   * backward sampling = suffix scan of the random maps g_t : X_{t+1} -> X_t
 //     (each map is the inverse-CDF draw for a fixed pre-drawn uniform), composed
 //     as 4-bit-per-entry tables;
-//   * sufficient statistics and transition counts = wave ballots / butterflies.
+//   * sufficient statistics: one pass, pivoted on the state means, wave ballots for the
+//     counts and DPP reductions for the sums.
+//   * wave specialisation: wave 0 draws the parameters (short serial phase) while the
+//     other waves, in its shadow, (a) write the previous sweep's per-draw outputs and
+//     forecast, (b) generate this sweep's uniforms for the state draws, and (c) prepare
+//     the state-independent parts of the NEXT sweep's parameter draws (Philox blocks,
+//     Box-Muller normals, log-uniforms, the rho Dirichlet) -- the RNG is counter-based,
+//     so none of that depends on the chain.
 // Only per-draw outputs (3K + K^2 + 2H doubles) leave the chip per sweep.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -50,6 +57,7 @@ struct KernelParams {
     int32_t* status;
     const int32_t* x_init; int32_t* x_final; double* pif_final; uint8_t* xstate; double* sumacc;
     const uint32_t* window_ids;
+    unsigned long long* dbg;   // diagnostic (HMCG_STAMPS) builds only: per-wave phase cycle sums
 };
 
 // ------------------------------------------------------------------ RNG ----
@@ -91,44 +99,83 @@ __device__ __forceinline__ double box_muller(const uint32_t (&r)[4])
     return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2);
 }
 
-// Gamma(shape,1): shape==1 -> exponential; shape>1 -> Marsaglia-Tsang; shape<1 -> boost.
-__device__ inline double gamma_draw(const Rng& g, uint32_t site, uint32_t elem, double shape, int& status)
+// Marsaglia-Tsang acceptance for one attempt: returns the variate or a negative number.
+__device__ __forceinline__ double mt_try(double d, double c, double x, double logu)
 {
-    uint32_t r[4];
-    if (shape == 1.0) {
-        g.block(site, elem, 0, r);
-        return -log(1.0 - u53(r[0], r[1]));
-    }
-    const double a = shape < 1.0 ? shape + 1.0 : shape;
-    const double d = a - 1.0 / 3.0;
-    const double c = 1.0 / sqrt(9.0 * d);
-    double out = d;
-    int j = 0;
-    for (; j < GAMMA_MAX_ATTEMPTS; ++j) {
-        g.block(site, elem, 2u * (uint32_t)j, r);
-        const double x = box_muller(r);
-        g.block(site, elem, 2u * (uint32_t)j + 1u, r);
-        const double u = u53(r[0], r[1]);
-        double v = 1.0 + c * x;
-        if (v <= 0.0) continue;
-        v = v * v * v;
-        if (log(1.0 - u) < 0.5 * x * x + d - d * v + d * log(v)) { out = d * v; break; }
-    }
-    if (j == GAMMA_MAX_ATTEMPTS) status |= HMCG_ST_GAMMA_CAP;
-    if (shape < 1.0) {
-        g.block(site, elem, 0xFFFFFFFFu, r);
-        out *= pow(1.0 - u53(r[0], r[1]), 1.0 / shape);
-    }
-    return out;
+    const double v1 = 1.0 + c * x;
+    const double v = v1 * v1 * v1;
+    const bool ok = (v1 > 0.0) && (logu < 0.5 * x * x + d - d * v + d * log(v));
+    return ok ? d * v : -1.0;
 }
 
-// ------------------------------------------------------- wave helpers ----
+// ------------------------------------------------------------- math ------
 
+// exp(x) for x <= ~0 (emission pdfs): Cody-Waite reduction by ln2 and a degree-13 Taylor
+// polynomial on |r| <= ln2/2 (truncation < 2e-17), scaled by ldexp (gradual underflow).
+__device__ __forceinline__ double exp_fast(double x)
+{
+    x = fmax(x, -746.0);                       // exp(-746) rounds to 0 in binary64
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// 1/x: hardware reciprocal + one Newton step (<= 1 ulp; within the parity tolerance)
+__device__ __forceinline__ double rcp_fast(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// ------------------------------------------------------- DPP helpers -----
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// lanes with no source (row edge, masked row) receive `old`
+template <int CTRL, int RMASK>
+__device__ __forceinline__ int dpp_i32(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, RMASK, 0xF, false);
+}
+template <int CTRL, int RMASK>
+__device__ __forceinline__ double dpp_f64(double old, double v)
+{
+    const int lo = dpp_i32<CTRL, RMASK>(__double2loint(old), __double2loint(v));
+    const int hi = dpp_i32<CTRL, RMASK>(__double2hiint(old), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// wave-wide sum, fixed association order (deterministic), broadcast to every lane
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_f64<DPP_ROW_SHR1, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_SHR2, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_SHR4, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_SHR8, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, v);
+    v += dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, v);
+    return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_min(double v)
 {
@@ -154,6 +201,28 @@ __device__ __forceinline__ void rescale_pow2(double (&q)[N])
     const int e = (m > 0.0 && m < 1.0e300) ? -ilogb(m) - 1 : 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) q[i] = ldexp(q[i], e);
+}
+
+// one level of the wave-wide inclusive matrix scan: Q <- (Q of the source lane) * Q
+template <int K, int CTRL, int RMASK>
+__device__ __forceinline__ void scan_level(double (&Q)[K * K])
+{
+    double O[K * K], N[K * K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int s = 0; s < K; ++s) O[r * K + s] = dpp_f64<CTRL, RMASK>((r == s) ? 1.0 : 0.0, Q[r * K + s]);
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            double acc = O[r * K] * Q[s];
+#pragma unroll
+            for (int k = 1; k < K; ++k) acc = fma(O[r * K + k], Q[k * K + s], acc);
+            N[r * K + s] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) Q[i] = N[i];
 }
 
 // 4-bit-per-entry state maps (K <= 8).  entry s of map m: (m >> 4s) & 15.
@@ -251,22 +320,40 @@ __device__ inline double forecast_value(const double (&mu)[K], const double (&A)
 
 // ---------------------------------------------------------------- LDS ----
 
-template <int K, int NT>
+template <int K>
+struct ThetaBuf {                 // one sweep's parameters, UNSORTED labels
+    double mu[K], sig2[K], isd[K], coef[K], rho[K];
+    double A[K][K];
+    double pi_end[K];             // unsorted pif[T-1,:] of that sweep
+};
+
+template <int K>
+struct RngBuf {                   // state-independent parts of one sweep's parameter draws
+    static constexpr int NG = K + K * K;      // gamma roles: sig2_i (K) then A_ij (K*K, row-major)
+    double x[NG][2];              // Box-Muller normal of attempts 0,1
+    double lu[NG][2];             // log(1-u) of attempts 0,1
+    double z[K];                  // normals for mu_i
+    double rho[K];                // the complete rho ~ Dirichlet(1) draw
+};
+
+template <int K, int L, int NT>
 struct SweepShared {
     static constexpr int NW = NT / 64;
-    int red_cnt[NW][K + K * K];   // per-wave state counts and transition counts
-    double red_sum[NW][K];        // per-wave sums of Y by state
-    double red_sse[NW][K];        // per-wave sums of squared deviations by state
-    double th_mu[K], th_sig2[K], th_isd[K], th_coef[K], th_rho[K];
-    double th_A[K][K];
+    static constexpr int NCNT = K + K * K;
+    int red_cnt[NW][NCNT];        // per-wave state counts and transition counts
+    double red_d1[NW][K];         // per-wave sums of (y - pivot_i) by state
+    double red_d2[NW][K];         // per-wave sums of (y - pivot_i)^2 by state
+    double pivot[K];              // pivots the partial sums above were taken about
+    ThetaBuf<K> th[2];            // parity = sweep & 1
+    RngBuf<K> rb[2];
     double wtot[NW][K * K];       // forward scan: wave totals
     double pfirst[NT + 1][K];     // filtered probs at each thread's first step
-    double pi_end[K];             // unsorted pif[T-1,:]
     uint32_t wmap[NW];            // backward scan: wave totals
     int xlast;                    // X[T-1]
     int xfirst[NT + 1];           // init only: first state of each thread's chunk
     double bred[NW];              // generic block reductions (init)
     double med[2];
+    double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
 };
 
 template <int NW>
@@ -294,20 +381,58 @@ __device__ __forceinline__ double block_minmax(double v, double* bred, int wave,
     return t;
 }
 
+// sortperm(mu) (src/Hmc.jl:501): stable rank of each entry
+template <int K>
+__device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K])
+{
+    int pos[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) c += (mu[j] < mu[i] || (mu[j] == mu[i] && j < i)) ? 1 : 0;
+        pos[i] = c;
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) o += (pos[i] == q) ? i : 0;
+        order[q] = o;
+    }
+}
+
+// In-kernel phase stamps: compiled only into the diagnostic build (-DHMCG_STAMPS, see
+// csrc/Makefile `stamps`); the shipped kernel executes none.  Values leave the kernel only
+// through p.dbg, which no other code reads.
+#ifdef HMCG_STAMPS
+#define HMCG_NSTAMP 14
+#define STAMP(i)                                                          \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        stamp_acc[i] += t_ - stamp_prev;                                  \
+        stamp_prev = t_;                                                  \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 // ------------------------------------------------------------- kernel ----
 
 template <int K, int L, int NT>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 {
-    static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter draws fit one wave");
-    static_assert(NT % 64 == 0 && NT >= 64, "whole waves");
+    static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter-draw roles fit one wave");
+    static_assert(NT % 64 == 0 && NT >= 128, "at least two whole waves (wave 0 draws, the others work in its shadow)");
     constexpr int NW = NT / 64;
     constexpr int KK = K * K;
-    constexpr int ND = 2 * K + KK;       // parameter-draw roles: sig2/mu (K), rho (K), A (K*K)
-    static_assert(ND <= 64, "draw roles must fit wave 0");
-
-    extern __shared__ double dyn_lds[];  // init only: Y staged for the median (NT*L doubles)
-    __shared__ SweepShared<K, NT> sh;
+    constexpr int NG = K + KK;           // gamma roles: sig2_i, then A_ij row-major
+    static_assert(NG <= 64, "draw roles must fit wave 0");
+    using Sh = SweepShared<K, L, NT>;
+    __shared__ Sh sh;
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -323,13 +448,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     // ---- load the window's observations (once per launch) ----
     double y[L];
     int x[L];
-    bool valid[L];
     bool bad = false;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        valid[l] = (t0 + l) < T;
-        y[l] = valid[l] ? p.Y[(size_t)w * p.ldY + t0 + l] : 0.0;
-        bad |= valid[l] && !isfinite(y[l]);
+        const bool v = (t0 + l) < T;
+        y[l] = v ? p.Y[(size_t)w * p.ldY + t0 + l] : 0.0;
+        bad |= v && !isfinite(y[l]);
         x[l] = 0;
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
@@ -341,15 +465,23 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     double part = 0.0;
 #pragma unroll
     for (int l = 0; l < L; ++l) part += y[l];
-    const double ymean = block_sum<NW>(part, sh.bred, wave, lane) / (double)T;
-    const double xi = ymean;
+    const double xi = block_sum<NW>(part, sh.bred, wave, lane) / (double)T;
 
+    double pivot[K];                     // pivots of the one-pass statistics (any value is exact in exact arithmetic)
+#pragma unroll
+    for (int k = 0; k < K; ++k) pivot[k] = xi;
+
+    const int NCK = 3 * K + K * K + 2 * p.H + K;      // checkpoint block: summary sums + pivots
     if (p.resume) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (valid[l]) x[l] = p.xstate[(size_t)w * p.ldY + t0 + l];
+        for (int l = 0; l < L; ++l) if (t0 + l < T) x[l] = p.xstate[(size_t)w * p.ldY + t0 + l];
+        if (p.sumacc) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) pivot[k] = p.sumacc[(size_t)w * NCK + (NCK - K) + k];
+        }
     } else if (p.x_init) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (valid[l]) x[l] = p.x_init[(size_t)w * p.ldY + t0 + l];
+        for (int l = 0; l < L; ++l) if (t0 + l < T) x[l] = p.x_init[(size_t)w * p.ldY + t0 + l];
     } else {
         // ---- makeParams (src/Hmc.jl:161-195): mu spread around the median, X = argmax pdf.
         // The initial "sigma" (= std(Y), :177) is the same for every state and is overwritten by the
@@ -358,45 +490,52 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         // decision does not depend on the exp implementation (see oracle/hmc_oracle.c chain_init).
         double lmin = 1.0e308, lmax = -1.0e308;
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (valid[l]) { lmin = fmin(lmin, y[l]); lmax = fmax(lmax, y[l]); }
+        for (int l = 0; l < L; ++l) if (t0 + l < T) { lmin = fmin(lmin, y[l]); lmax = fmax(lmax, y[l]); }
         const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
         const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
         // median by rank counting over the LDS-staged window
 #pragma unroll
-        for (int l = 0; l < L; ++l) dyn_lds[t0 + l] = y[l];
+        for (int l = 0; l < L; ++l) sh.ux[t0 + l] = y[l];
         __syncthreads();
         int rank[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) rank[l] = 0;
         for (int j = 0; j < T; ++j) {
-            const double yj = dyn_lds[j];
+            const double yj = sh.ux[j];
 #pragma unroll
             for (int l = 0; l < L; ++l) rank[l] += (yj < y[l] || (yj == y[l] && j < t0 + l)) ? 1 : 0;
         }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if (valid[l] && rank[l] == (T - 1) / 2) sh.med[0] = y[l];
-            if (valid[l] && rank[l] == T / 2) sh.med[1] = y[l];
+            if (t0 + l < T && rank[l] == (T - 1) / 2) sh.med[0] = y[l];
+            if (t0 + l < T && rank[l] == T / 2) sh.med[1] = y[l];
         }
         __syncthreads();
-        const double med = (T & 1) ? sh.med[0] : sh.med[0] / 2 + sh.med[1] / 2;
-        const double R = ymax - ymin;
-        const double lo = med - 0.25 * R, hi = med + 0.25 * R;
-        double mu0[K];
+        {
+            // bit-identical to the oracle: no FMA contraction in this block (tie rule, see above)
+#pragma clang fp contract(off)
+            const double med = (T & 1) ? sh.med[0] : sh.med[0] / 2 + sh.med[1] / 2;
+            const double R = ymax - ymin;
+            const double lo = med - 0.25 * R, hi = med + 0.25 * R;
+            double mu0[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) mu0[k] = lo + (hi - lo) * ((double)k / (double)(K - 1));
-        mu0[K - 1] = hi;
+            for (int k = 0; k < K; ++k) mu0[k] = lo + (hi - lo) * ((double)k / (double)(K - 1));
+            mu0[K - 1] = hi;
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            int best = 0;
-            double bd = fabs(y[l] - mu0[0]);
+            for (int l = 0; l < L; ++l) {
+                int best = 0;
+                double bd = fabs(y[l] - mu0[0]);
 #pragma unroll
-            for (int k = 1; k < K; ++k) {
-                const double d = fabs(y[l] - mu0[k]);
-                if (d < bd) { bd = d; best = k; }
+                for (int k = 1; k < K; ++k) {
+                    const double d = fabs(y[l] - mu0[k]);
+                    if (d < bd) { bd = d; best = k; }
+                }
+                x[l] = (t0 + l < T) ? best : 0;
             }
-            x[l] = valid[l] ? best : 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) pivot[k] = mu0[k];
         }
+        __syncthreads();                 // sh.ux is reused by the sweeps
     }
 
     // first state of the next thread's chunk (X at t0+L)
@@ -406,182 +545,288 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     __syncthreads();
     xnext = sh.xfirst[tid + 1];
 
-    // running sums behind `summary`
-    constexpr int NSMAX = 3 * K + KK + 2 * HMCG_MAXH;
-    const int NS = 3 * K + KK + 2 * p.H;
-    const int orole = tid - (NT - 64);          // output roles live in the last wave
-    double sum_acc = 0.0;
-    if (orole >= 0 && orole < NS && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NS + orole];
-    (void)NSMAX;
-
     Rng rng{p.seed_lo, p.seed_hi, p.window_ids ? p.window_ids[w] : p.window_base + (uint32_t)w, 0u};
+    const int NS = 3 * K + KK + 2 * p.H;
 
-    // per-wave partial statistics of the current X (pass 1): counts, sums, transitions
+    // ======================= shadow jobs (waves 1..NW-1) ======================
+    const int shadow_wave = wave - 1;                  // -1 on wave 0
+    constexpr int NSH = NW - 1;
+
+    // normals for the gamma attempts and for mu of sweep `sw` -> sh.rb[sw & 1]
+    auto job_normals = [&](int sw, int l0, int nl) {
+        Rng g = rng;
+        g.sweep = (uint32_t)sw;
+        RngBuf<K>& rb = sh.rb[sw & 1];
+        for (int task = l0; task < 2 * NG + K; task += nl) {
+            uint32_t r[4];
+            if (task < 2 * NG) {
+                const int role = task >> 1, j = task & 1;
+                const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
+                const uint32_t elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
+                g.block(site, elem, 2u * (uint32_t)j, r);
+                rb.x[role][j] = box_muller(r);
+            } else {
+                g.block(SITE_MU, (uint32_t)(task - 2 * NG), 0, r);
+                rb.z[task - 2 * NG] = box_muller(r);
+            }
+        }
+    };
+    // log(1-u) for the gamma attempts, and the whole rho draw, of sweep `sw`
+    auto job_logs = [&](int sw, int l0, int nl) {
+        Rng g = rng;
+        g.sweep = (uint32_t)sw;
+        RngBuf<K>& rb = sh.rb[sw & 1];
+        for (int task = l0; task < 2 * NG; task += nl) {
+            uint32_t r[4];
+            const int role = task >> 1, j = task & 1;
+            const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
+            const uint32_t elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
+            g.block(site, elem, 2u * (uint32_t)j + 1u, r);
+            rb.lu[role][j] = log(1.0 - u53(r[0], r[1]));
+        }
+        if (l0 == nl - 1) {               // rho ~ Dirichlet(ones(K)) (:350-356): K exponentials, normalised (last lane of the job)
+            double e[K], s = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                uint32_t r[4];
+                g.block(SITE_RHO, (uint32_t)i, 0, r);
+                e[i] = -log(1.0 - u53(r[0], r[1]));
+                s += e[i];
+            }
+            const double inv = 1.0 / s;
+#pragma unroll
+            for (int i = 0; i < K; ++i) rb.rho[i] = e[i] * inv;
+        }
+    };
+    // uniforms for the state draws of sweep `sw` (site 4, index t): block b covers t = 2b, 2b+1
+    auto job_uniforms = [&](int sw, int l0, int nl) {
+        Rng g = rng;
+        g.sweep = (uint32_t)sw;
+        const int nblk = (T + 1) >> 1;
+        for (int b = l0; b < nblk; b += nl) {
+            uint32_t r[4];
+            g.block(SITE_X, 0, (uint32_t)b, r);
+            sh.ux[2 * b] = u53(r[0], r[1]);
+            if (2 * b + 1 < NT * L) sh.ux[2 * b + 1] = u53(r[2], r[3]);
+        }
+    };
+
+    // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1]); lanes [0,NS) of one wave
+    double sum_acc = 0.0;                 // running sum behind `summary` (meaningful on the output lanes only)
+    constexpr int OUT_WAVE = 1;           // the wave that owns the output lanes
+    const int orole = (wave == OUT_WAVE) ? lane : -1;
+    if (orole >= 0 && orole < NS && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
+    auto job_outputs = [&](int sw) {
+        if (sw < p.keep_from || orole < 0 || orole >= NS) return;
+        const ThetaBuf<K>& th = sh.th[sw & 1];
+        const int d = sw - p.keep_from;
+        double mu_u[K];
+        int order[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) mu_u[i] = th.mu[i];
+        sort_order<K>(mu_u, order);
+        const size_t nrun = (size_t)p.nrun;
+        double val = 0.0;
+        double* dst = nullptr;
+        if (orole < 3 * K) {
+            const int q = orole % K, which = orole / K;     // 0 mu, 1 sig2, 2 pi_end, sorted position q
+            int src = 0;
+#pragma unroll
+            for (int qq = 0; qq < K; ++qq) src = (qq == q) ? order[qq] : src;
+            val = which == 0 ? th.mu[src] : (which == 1 ? th.sig2[src] : th.pi_end[src]);
+            double* base = which == 0 ? p.mu : (which == 1 ? p.sig2 : p.pi_end);
+            if (base) dst = base + nrun * ((size_t)q + (size_t)K * w) + d;
+        } else if (orole < 3 * K + KK) {
+            const int e = orole - 3 * K;                    // column-major: e = i + K*j (src/Hmc.jl:745)
+            const int i0 = e % K, j0 = e / K;
+            int si = 0, sj = 0;
+#pragma unroll
+            for (int qq = 0; qq < K; ++qq) { si = (qq == i0) ? order[qq] : si; sj = (qq == j0) ? order[qq] : sj; }
+            val = th.A[si][sj];                             // A[i1,j1] = Atmp[order[i1], order[j1]] (:506-511)
+            if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + d;
+        } else {
+            const int e = orole - 3 * K - KK;               // 2h + {0: forecast, 1: error}
+            const int h = e >> 1;
+            double smu[K], spe[K], sA[K][K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) { smu[q] = th.mu[order[q]]; spe[q] = th.pi_end[order[q]]; }
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int q2 = 0; q2 < K; ++q2) sA[q][q2] = th.A[order[q]][order[q2]];
+            const double fv = forecast_value<K>(smu, sA, spe, p.horizons[h]);
+            const double yr = p.yreal ? p.yreal[(size_t)w * p.H + h] : __builtin_nan("");
+            val = (e & 1) ? fv - yr : fv;
+            if (p.fcast) dst = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w) + d;
+        }
+        if (dst) *dst = val;
+        sum_acc += round5(val);
+    };
+
+    // per-wave partial statistics of the current X: counts, pivoted sums, transitions
     auto publish_stats = [&]() {
+#pragma unroll
+        for (int k = 0; k < K; ++k) if (tid == k) sh.pivot[k] = pivot[k];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             int c = 0;
-            double s = 0.0;
+            double d1 = 0.0, d2 = 0.0;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                const bool hit = valid[l] && x[l] == i;
+                const bool hit = (t0 + l < T) && x[l] == i;
                 c += __popcll(__ballot(hit));
-                s += hit ? y[l] : 0.0;
+                const double dlt = y[l] - pivot[i];
+                d1 += hit ? dlt : 0.0;
+                d2 += hit ? dlt * dlt : 0.0;
             }
-            s = wave_sum(s);
-            if (lane == 0) { sh.red_cnt[wave][i] = c; sh.red_sum[wave][i] = s; }
+            d1 = wave_sum(d1);
+            d2 = wave_sum(d2);
+            if (lane == 0) { sh.red_cnt[wave][i] = c; sh.red_d1[wave][i] = d1; sh.red_d2[wave][i] = d2; }
+        }
+        int code[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int xn = (l + 1 < L) ? x[(l + 1 < L) ? l + 1 : l] : xnext;
+            code[l] = (t0 + l + 1 < T) ? x[l] * K + xn : -1;
         }
 #pragma unroll
-        for (int i = 0; i < K; ++i)
+        for (int e = 0; e < KK; ++e) {
+            int c = 0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                int c = 0;
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    const int xn = (l + 1 < L) ? x[(l + 1 < L) ? l + 1 : l] : xnext;
-                    const bool hit = (t0 + l + 1 < T) && x[l] == i && xn == j;
-                    c += __popcll(__ballot(hit));
-                }
-                if (lane == 0) sh.red_cnt[wave][K + i * K + j] = c;
-            }
+            for (int l = 0; l < L; ++l) c += __popcll(__ballot(code[l] == e));
+            if (lane == 0) sh.red_cnt[wave][K + e] = c;
+        }
     };
     publish_stats();
 
+    // prologue: the first sweep's state-independent RNG parts
+    if (p.sweep_begin < p.sweep_end && shadow_wave == 0) {
+        job_normals(p.sweep_begin, lane, 64);
+        job_logs(p.sweep_begin, lane, 64);
+    }
+
     double pf[L][K];     // unsorted filtered probabilities of this thread's steps
+#ifdef HMCG_STAMPS
+    unsigned long long stamp_acc[HMCG_NSTAMP];
+    for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
         rng.sweep = (uint32_t)sweep;
-        __syncthreads();                                                     // B0
-        // ---- totals of pass 1 ----
-        int Ni[K];
-        double Si[K], ybar[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            int c = 0;
-            double s = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) { c += sh.red_cnt[ww][i]; s += sh.red_sum[ww][i]; }
-            Ni[i] = c; Si[i] = s;
-            ybar[i] = c > 0 ? s / (double)c : 0.0;                           // :259-265
-        }
-        // ---- pass 2: squared deviations about the state mean (:291-294) ----
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double s2 = 0.0;
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const double dlt = y[l] - ybar[i];
-                s2 += (valid[l] && x[l] == i) ? dlt * dlt : 0.0;
-            }
-            s2 = wave_sum(s2);
-            if (lane == 0) sh.red_sse[wave][i] = s2;
-        }
-        __syncthreads();                                                     // B1
-        // ---- parameter draws on wave 0 (sites 0..3) ----
+        const int par = sweep & 1;
+        ThetaBuf<K>& th = sh.th[par];
+        __syncthreads();                                                     // Ba: statistics + rb[par] ready
+        STAMP(0);
         if (wave == 0) {
-            double val = 0.0;     // this lane's gamma variate
+            // ---- parameter draws (sites 0,1,3; site 2 = rho comes ready-made from the shadow) ----
+            const RngBuf<K>& rb = sh.rb[par];
             const int role = lane;
-            const bool is_sig = role < K, is_rho = role >= K && role < 2 * K, is_A = role >= 2 * K && role < ND;
-            double shape = 1.0, bpar = 1.0, Neff = 0.0;
-            uint32_t site = SITE_RHO, elem = 0;
-            if (is_sig) {
-                const int i = role;
-                int c = 0; double s = 0.0, s2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) if (k == i) { c = Ni[k]; s = Si[k]; }
-#pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s2 += sh.red_sse[ww][i];
-                Neff = (double)c;
-                const double tb = c > 0 ? s / (double)c : 0.0;               // totalbar (:282-288, Mi=0)
-                const double beta = (sweep == 0) ? 1.0 : 2.0;                // quirk 2 (:179, :347)
-                const double dm = tb - xi;
-                shape = p.alpha + 0.5 * Neff;                                // :313
-                bpar = beta + 0.5 * s2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
-                site = SITE_SIG2; elem = (uint32_t)i;
-            } else if (is_rho) {
-                site = SITE_RHO; elem = (uint32_t)(role - K);
-            } else if (is_A) {
-                const int e = role - 2 * K;
+            const bool is_sig = role < K, is_g = role < NG;
+            double shape = 1.0, bpar = 1.0, Neff = 0.0, Ssum = 0.0;
+            if (is_g) {
                 int c = 0;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) c += sh.red_cnt[ww][K + e];
-                shape = (double)(c + 1);                                     // :362-365
-                site = SITE_A; elem = (uint32_t)e;
+                for (int ww = 0; ww < NW; ++ww) c += sh.red_cnt[ww][role];      // N_i for sig roles, C_ij for A roles
+                if (is_sig) {
+                    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) { d1 += sh.red_d1[ww][role]; d2 += sh.red_d2[ww][role]; }
+                    const double piv = sh.pivot[role];
+                    Neff = (double)c;
+                    const double rn = c > 0 ? 1.0 / Neff : 0.0;
+                    const double ybar = c > 0 ? piv + d1 * rn : 0.0;             // :259-265, :282-288
+                    const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;  // sum (y-ybar)^2 (:291-294)
+                    Ssum = piv * Neff + d1;                                      // sum of y in the state
+                    const double beta = (sweep == 0) ? 1.0 : 2.0;                // quirk 2 (:179, :347)
+                    const double dm = ybar - xi;
+                    shape = p.alpha + 0.5 * Neff;                                // :313
+                    bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
+                } else {
+                    shape = (double)(c + 1);                                     // :362-365
+                }
             }
-            if (role < ND) val = gamma_draw(rng, site, elem, shape, st);
-            // normalise the Dirichlet rows: sum the group's variates in element order
-            const int gbase = is_A ? 2 * K + ((role - 2 * K) / K) * K : K;
+            double val = 1.0;
+            if (is_g) {
+                const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
+                const uint32_t elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
+                if (shape == 1.0) {
+                    // Gamma(1) = exponential of block index 0: only for a never-visited state pair; inline
+                    uint32_t r[4];
+                    rng.block(site, elem, 0, r);
+                    val = -log(1.0 - u53(r[0], r[1]));
+                } else {
+                    const double a = shape < 1.0 ? shape + 1.0 : shape;
+                    const double dd = a - 1.0 / 3.0;
+                    const double cc = 1.0 / sqrt(9.0 * dd);
+                    val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0]);
+                    if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1]);
+                    if (val < 0.0) {
+                        // third and later attempts (rare): inline Philox
+                        int j = 2;
+                        for (; j < GAMMA_MAX_ATTEMPTS && val < 0.0; ++j) {
+                            uint32_t r[4];
+                            rng.block(site, elem, 2u * (uint32_t)j, r);
+                            const double xx = box_muller(r);
+                            rng.block(site, elem, 2u * (uint32_t)j + 1u, r);
+                            val = mt_try(dd, cc, xx, log(1.0 - u53(r[0], r[1])));
+                        }
+                        if (val < 0.0) { val = dd; st |= HMCG_ST_GAMMA_CAP; }
+                    }
+                    if (shape < 1.0) {
+                        uint32_t r[4];
+                        rng.block(site, elem, 0xFFFFFFFFu, r);
+                        val *= pow(1.0 - u53(r[0], r[1]), 1.0 / shape);
+                    }
+                }
+            }
+            // normalise the Dirichlet rows of A: sum the row's variates in column order (:367)
+            const int gbase = (role >= K && is_g) ? K + ((role - K) / K) * K : K;
             double gs = 0.0;
 #pragma unroll
             for (int j = 0; j < K; ++j) gs += __shfl(val, gbase + j, 64);
-            const double ginv = 1.0 / gs;
             if (is_sig) {
-                const int i = role;
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) if (k == i) s = Si[k];
-                const double sig2 = 1.0 / (val * (1.0 / bpar));              // :320 InverseGamma(a,b)
-                const double m = (s + p.nu * xi) / (Neff + p.nu);            // :331
-                const double sdev = sqrt(sig2 / (Neff + p.nu));              // :332
-                uint32_t r[4];
-                rng.block(SITE_MU, (uint32_t)i, 0, r);
-                const double mu = m + sdev * box_muller(r);                  // :334
-                const double sd = sqrt(sig2);                                // :381
-                sh.th_mu[i] = mu; sh.th_sig2[i] = sig2;
-                sh.th_isd[i] = 1.0 / sd; sh.th_coef[i] = INVSQRT2PI / sd;
-            } else if (is_rho) {
-                sh.th_rho[role - K] = val * ginv;                            // :355
-            } else if (is_A) {
-                const int e = role - 2 * K;
-                sh.th_A[e / K][e % K] = val * ginv;                          // :367
+                const double sig2 = 1.0 / (val * (1.0 / bpar));                  // :320 InverseGamma(a,b)
+                const double m = (Ssum + p.nu * xi) / (Neff + p.nu);             // :331
+                const double sdev = sqrt(sig2 / (Neff + p.nu));                  // :332
+                const double mu = m + sdev * rb.z[role];                         // :334
+                const double sd = sqrt(sig2);                                    // :381
+                th.mu[role] = mu; th.sig2[role] = sig2;
+                th.isd[role] = 1.0 / sd; th.coef[role] = INVSQRT2PI / sd;
+                th.rho[role] = rb.rho[role];                                     // :355
+            } else if (is_g) {
+                const int e = role - K;
+                th.A[e / K][e % K] = val * (1.0 / gs);
+            }
+        } else {
+            // ---- shadow of the parameter draws ----
+            if (shadow_wave == 0 && sweep > p.sweep_begin) job_outputs(sweep - 1);
+            if (NSH >= 3) {
+                // wave 1: outputs; waves 2..: the RNG preparation and the uniforms
+                if (shadow_wave == 1 && sweep + 1 < p.sweep_end) job_normals(sweep + 1, lane, 64);
+                if (shadow_wave == 2 && sweep + 1 < p.sweep_end) job_logs(sweep + 1, lane, 64);
+                if (shadow_wave >= 1) job_uniforms(sweep, (shadow_wave - 1) * 64 + lane, (NSH - 1) * 64);
+            } else {
+                if (shadow_wave == NSH - 1 && sweep + 1 < p.sweep_end) { job_normals(sweep + 1, lane, 64); job_logs(sweep + 1, lane, 64); }
+                job_uniforms(sweep, shadow_wave * 64 + lane, NSH * 64);
             }
         }
-        __syncthreads();                                                     // B2
-        // ---- everyone: parameters to registers, label order (sortperm, :501) ----
+        STAMP(1);
+        __syncthreads();                                                     // Bb: theta[par], ux ready
+        STAMP(2);
+        // ---- everyone: parameters to registers ----
         double mu[K], isd[K], coef[K], rho[K], A[K][K];
         int order[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            mu[i] = sh.th_mu[i]; isd[i] = sh.th_isd[i]; coef[i] = sh.th_coef[i]; rho[i] = sh.th_rho[i];
+            mu[i] = th.mu[i]; isd[i] = th.isd[i]; coef[i] = th.coef[i]; rho[i] = th.rho[i];
 #pragma unroll
-            for (int j = 0; j < K; ++j) A[i][j] = sh.th_A[i][j];
+            for (int j = 0; j < K; ++j) A[i][j] = th.A[i][j];
         }
-        {
-            int pos[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < K; ++j) c += (mu[j] < mu[i] || (mu[j] == mu[i] && j < i)) ? 1 : 0;
-                pos[i] = c;
-            }
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                int o = 0;
-#pragma unroll
-                for (int i = 0; i < K; ++i) o += (pos[i] == q) ? i : 0;
-                order[q] = o;
-            }
-        }
-        // ---- uniforms for the state draws (site 4, index t) ----
+        sort_order<K>(mu, order);
         double ux[L];
-        if constexpr (L % 2 == 0) {
 #pragma unroll
-            for (int b = 0; b < L / 2; ++b) {
-                uint32_t r[4];
-                rng.block(SITE_X, 0, (uint32_t)(t0 / 2 + b), r);
-                ux[2 * b] = u53(r[0], r[1]);
-                ux[2 * b + 1] = u53(r[2], r[3]);
-            }
-        } else {
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                uint32_t r[4];
-                const uint32_t t = (uint32_t)(t0 + l);
-                rng.block(SITE_X, 0, t >> 1, r);
-                ux[l] = (t & 1u) ? u53(r[2], r[3]) : u53(r[0], r[1]);
-            }
-        }
+        for (int l = 0; l < L; ++l) ux[l] = sh.ux[t0 + l];
         // ---- forward filter (:371-440) as a scan of M_t = A diag(f_t) ----
         double f[L][K];
 #pragma unroll
@@ -590,12 +835,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 const double z = (y[l] - mu[s]) * isd[s];
-                f[l][s] = exp(-(z * z) / 2.0) * coef[s];
+                f[l][s] = exp_fast(-0.5 * (z * z)) * coef[s];
                 fm = fmax(fm, f[l][s]);
             }
             if (!(fm >= 1e-300)) {
                 // every pdf underflowed: treat the observation as missing (f = 1) and flag the window
-                if (valid[l]) st |= HMCG_ST_EMIS_UNDERFLOW;
+                if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
                 for (int s = 0; s < K; ++s) f[l][s] = 1.0;
             } else {
@@ -604,102 +849,91 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 for (int s = 0; s < K; ++s) f[l][s] = ldexp(f[l][s], e);
             }
         }
+        STAMP(3);
         // local product Q = M_{t0} ... M_{t0+L-1} (identity for padded steps)
         double Q[KK];
 #pragma unroll
         for (int r = 0; r < K; ++r)
 #pragma unroll
-            for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
+            for (int s = 0; s < K; ++s) Q[r * K + s] = (t0 < T) ? A[r][s] * f[0][s] : ((r == s) ? 1.0 : 0.0);
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            if (valid[l]) {
-                double N[KK];
+        for (int l = 1; l < L; ++l) {
+            double N[KK];
 #pragma unroll
-                for (int r = 0; r < K; ++r)
+            for (int r = 0; r < K; ++r)
 #pragma unroll
-                    for (int s = 0; s < K; ++s) {
-                        double acc = 0.0;
+                for (int s = 0; s < K; ++s) {
+                    double acc = Q[r * K] * A[0][s];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) acc += Q[r * K + k] * A[k][s];
-                        N[r * K + s] = acc * f[l][s];
-                    }
+                    for (int k = 1; k < K; ++k) acc = fma(Q[r * K + k], A[k][s], acc);
+                    N[r * K + s] = acc * f[l][s];
+                }
+            const bool v = (t0 + l) < T;
 #pragma unroll
-                for (int i = 0; i < KK; ++i) Q[i] = N[i];
-            }
+            for (int i = 0; i < KK; ++i) Q[i] = v ? N[i] : Q[i];
         }
         rescale_pow2<KK>(Q);
-        // Kogge-Stone inclusive scan over the wave (earlier lanes multiply on the left)
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            double O[KK];
-#pragma unroll
-            for (int i = 0; i < KK; ++i) O[i] = __shfl_up(Q[i], d, 64);
-            if (lane >= d) {
-                double N[KK];
-#pragma unroll
-                for (int r = 0; r < K; ++r)
-#pragma unroll
-                    for (int s = 0; s < K; ++s) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc += O[r * K + k] * Q[k * K + s];
-                        N[r * K + s] = acc;
-                    }
-#pragma unroll
-                for (int i = 0; i < KK; ++i) Q[i] = N[i];
-            }
-            rescale_pow2<KK>(Q);
-        }
+        STAMP(4);
+        // inclusive scan over the wave (earlier lanes multiply on the left); the per-step scaling
+        // keeps every factor's largest entry in [0.5,1), so rescaling every other level is ample
+        scan_level<K, DPP_ROW_SHR1, 0xF>(Q);
+        scan_level<K, DPP_ROW_SHR2, 0xF>(Q);
+        rescale_pow2<KK>(Q);
+        scan_level<K, DPP_ROW_SHR4, 0xF>(Q);
+        scan_level<K, DPP_ROW_SHR8, 0xF>(Q);
+        rescale_pow2<KK>(Q);
+        scan_level<K, DPP_ROW_BCAST15, 0xA>(Q);
+        scan_level<K, DPP_ROW_BCAST31, 0xC>(Q);
+        rescale_pow2<KK>(Q);
         if (lane == 63) {
 #pragma unroll
             for (int i = 0; i < KK; ++i) sh.wtot[wave][i] = Q[i];
         }
-        __syncthreads();                                                     // B3
+        STAMP(5);
+        __syncthreads();                                                     // Bc
+        STAMP(6);
         // prefix vector: rho' * (totals of earlier waves) * (exclusive lane prefix)
         double av[K];
 #pragma unroll
         for (int s = 0; s < K; ++s) av[s] = rho[s];
-        for (int ww = 0; ww < wave; ++ww) {
+#pragma unroll
+        for (int ww = 0; ww < NW - 1; ++ww) {
+            double nv[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double acc = av[0] * sh.wtot[ww][s];
+#pragma unroll
+                for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
+                nv[s] = acc;
+            }
+            rescale_pow2<K>(nv);
+#pragma unroll
+            for (int s = 0; s < K; ++s) av[s] = (ww < wave) ? nv[s] : av[s];
+        }
+        {
             double nv[K];
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 double acc = 0.0;
 #pragma unroll
-                for (int r = 0; r < K; ++r) acc += av[r] * sh.wtot[ww][r * K + s];
+                for (int r = 0; r < K; ++r)
+                    acc = fma(av[r], dpp_f64<DPP_WAVE_SHR1, 0xF>((r == s) ? 1.0 : 0.0, Q[r * K + s]), acc);
                 nv[s] = acc;
             }
             rescale_pow2<K>(nv);
 #pragma unroll
             for (int s = 0; s < K; ++s) av[s] = nv[s];
         }
-        {
-            double E[KK];
-#pragma unroll
-            for (int i = 0; i < KK; ++i) E[i] = __shfl_up(Q[i], 1, 64);
-            if (lane > 0) {
-                double nv[K];
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int r = 0; r < K; ++r) acc += av[r] * E[r * K + s];
-                    nv[s] = acc;
-                }
-#pragma unroll
-                for (int s = 0; s < K; ++s) av[s] = nv[s];
-            }
-            rescale_pow2<K>(av);
-        }
         // replay the normalised recursion over this thread's steps (:413-432)
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if (valid[l]) {
+            if (t0 + l < T) {
                 double nv[K], total = 0.0;
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    double acc = 0.0;
+                    double acc = av[0] * A[0][s];
 #pragma unroll
-                    for (int r = 0; r < K; ++r) acc += av[r] * A[r][s];
+                    for (int r = 1; r < K; ++r) acc = fma(av[r], A[r][s], acc);
                     nv[s] = acc * f[l][s];
                     total += nv[s];
                 }
@@ -709,7 +943,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                     for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
                     total = 1.0;
                 }
-                const double inv = 1.0 / total;
+                const double inv = rcp_fast(total);
 #pragma unroll
                 for (int s = 0; s < K; ++s) av[s] = nv[s] * inv;
             }
@@ -740,67 +974,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 if (q < K - 1) idx += (cp <= ulast) ? 1 : 0;
             }
 #pragma unroll
-            for (int s = 0; s < K; ++s) sh.pi_end[s] = pe[s];
+            for (int s = 0; s < K; ++s) th.pi_end[s] = pe[s];
             sh.xlast = idx;
         }
-        __syncthreads();                                                     // B4
-        // ---- per-draw outputs (last wave), d = index of the kept draw ----
-        if (sweep >= p.keep_from && orole >= 0 && orole < NS) {
-            const int d = sweep - p.keep_from;
-            double smu[K], ssig[K], spe[K], sA[K][K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-#pragma unroll
-                for (int s = 0; s < K; ++s)
-                    if (order[q] == s) { smu[q] = mu[s]; ssig[q] = sh.th_sig2[s]; spe[q] = sh.pi_end[s]; }
-            }
-#pragma unroll
-            for (int q = 0; q < K; ++q)
-#pragma unroll
-                for (int q2 = 0; q2 < K; ++q2) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int i = 0; i < K; ++i)
-#pragma unroll
-                        for (int j = 0; j < K; ++j) v = (order[q] == i && order[q2] == j) ? A[i][j] : v;
-                    sA[q][q2] = v;
-                }
-            double val = 0.0;
-            double* dst = nullptr;
-            const size_t nrun = (size_t)p.nrun;
-            if (orole < K) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) if (orole == q) val = smu[q];
-                if (p.mu) dst = p.mu + nrun * ((size_t)orole + (size_t)K * w) + d;
-            } else if (orole < 2 * K) {
-                const int q0 = orole - K;
-#pragma unroll
-                for (int q = 0; q < K; ++q) if (q0 == q) val = ssig[q];
-                if (p.sig2) dst = p.sig2 + nrun * ((size_t)q0 + (size_t)K * w) + d;
-            } else if (orole < 3 * K) {
-                const int q0 = orole - 2 * K;
-#pragma unroll
-                for (int q = 0; q < K; ++q) if (q0 == q) val = spe[q];
-                if (p.pi_end) dst = p.pi_end + nrun * ((size_t)q0 + (size_t)K * w) + d;
-            } else if (orole < 3 * K + KK) {
-                const int e = orole - 3 * K;          // column-major: e = i + K*j
-                const int i0 = e % K, j0 = e / K;
-#pragma unroll
-                for (int i = 0; i < K; ++i)
-#pragma unroll
-                    for (int j = 0; j < K; ++j) if (i0 == i && j0 == j) val = sA[i][j];
-                if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + d;
-            } else {
-                const int e = orole - 3 * K - KK;     // 2h + {0: forecast, 1: error}
-                const int h = e >> 1;
-                const double fv = forecast_value<K>(smu, sA, spe, p.horizons[h]);
-                const double yr = p.yreal ? p.yreal[(size_t)w * p.H + h] : __builtin_nan("");
-                val = (e & 1) ? fv - yr : fv;
-                if (p.fcast) dst = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w) + d;
-            }
-            if (dst) *dst = val;
-            sum_acc += round5(val);
-        }
+        STAMP(7);
+        __syncthreads();                                                     // Bd
+        STAMP(8);
         // ---- backward sampling (:459-484) as a suffix scan of state maps ----
         const int xlast = sh.xlast;
         double pfn_last[K];
@@ -811,36 +990,32 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
-            uint32_t m = map_identity<K>();
-            if (t == T - 1) {
-                m = map_const<K>(xlast);
-            } else if (t < T - 1) {
-                m = 0;
+            uint32_t m = 0;
 #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    // p[r] = Pf[t+1,r,s] is proportional to pif[t,r] * A[r,s]; its sum over r equals
-                    // the unsorted pif[t+1,s], which drives the eps() guard (:472, quirk 7)
-                    double wr[K], tot = 0.0;
+            for (int s = 0; s < K; ++s) {
+                // p[r] = Pf[t+1,r,s] is proportional to pif[t,r] * A[r,s]; its sum over r equals
+                // the unsorted pif[t+1,s], which drives the eps() guard (:472, quirk 7)
+                const double guard = (l + 1 < L) ? pf[(l + 1 < L) ? l + 1 : l][s] : pfn_last[s];
+                const bool gok = guard > EPS64;
+                double tot = 0.0;
+                double cum[K];
 #pragma unroll
-                    for (int r = 0; r < K; ++r) { wr[r] = pf[l][r] * A[r][s]; tot += wr[r]; }
-                    const double guard = (l + 1 < L) ? pf[(l + 1 < L) ? l + 1 : l][s] : pfn_last[s];
-                    int idx = 0;
-                    if (guard > EPS64) {
-                        const double thr = ux[l] * tot;
-                        double cp = 0.0;
-#pragma unroll
-                        for (int r = 0; r < K - 1; ++r) { cp += wr[r]; idx += (cp <= thr) ? 1 : 0; }
-                    } else {
-                        double cp = 0.0;
-#pragma unroll
-                        for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx += (cp <= ux[l]) ? 1 : 0; }
-                    }
-                    m |= (uint32_t)idx << (4 * s);
+                for (int r = 0; r < K; ++r) {
+                    const double wr = gok ? pf[l][r] * A[r][s] : 1.0 / K;       // uniform 1/K fallback (:476-480)
+                    tot += wr;
+                    cum[r] = tot;
                 }
+                const double thr = gok ? ux[l] * tot : ux[l];
+                int idx = 0;
+#pragma unroll
+                for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
+                m |= (uint32_t)idx << (4 * s);
             }
+            m = (t == T - 1) ? map_const<K>(xlast) : (t > T - 1 ? map_identity<K>() : m);
             gmap[l] = m;
             G = map_compose<K>(m, G);      // G = g_{t0+l} o (g_{t0+l+1} o ...)
         }
+        STAMP(9);
         // inclusive suffix scan over lanes: H_lane = G_lane o G_{lane+1} o ... o G_63
         uint32_t Hm = G;
 #pragma unroll
@@ -849,9 +1024,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             if (lane + d < 64) Hm = map_compose<K>(Hm, O);
         }
         if (lane == 0) sh.wmap[wave] = Hm;
-        __syncthreads();                                                     // B5
+        STAMP(10);
+        __syncthreads();                                                     // Be
+        STAMP(11);
         uint32_t Rw = map_identity<K>();
-        for (int ww = NW - 1; ww > wave; --ww) Rw = map_compose<K>(sh.wmap[ww], Rw);
+#pragma unroll
+        for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? map_compose<K>(sh.wmap[ww], Rw) : Rw;
         uint32_t Hx = __shfl_down(Hm, 1, 64);
         if (lane == 63) Hx = map_identity<K>();
         const uint32_t Sfx = map_compose<K>(Hx, Rw);   // everything after this thread's chunk
@@ -859,31 +1037,46 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         xnext = sin;
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
-            if (valid[l]) { sin = map_apply(gmap[l], sin); x[l] = sin; }
+            if (t0 + l < T) { sin = map_apply(gmap[l], sin); x[l] = sin; }
         }
+        // pivots for the next sweep's one-pass statistics: this sweep's state means (X labels are unsorted)
+#pragma unroll
+        for (int k = 0; k < K; ++k) pivot[k] = mu[k];
+        STAMP(12);
         publish_stats();
+        STAMP(13);
     }
+#ifdef HMCG_STAMPS
+    if (lane == 0 && p.dbg)
+        for (int i = 0; i < HMCG_NSTAMP; ++i) p.dbg[((size_t)w * NW + wave) * HMCG_NSTAMP + i] = stamp_acc[i];
+#endif
 
-    // ---- epilogue: checkpoint / debug outputs ----
+    // ---- epilogue: the last sweep's outputs, checkpoint / debug outputs ----
+    __syncthreads();
+    if (p.sweep_end > p.sweep_begin) job_outputs(p.sweep_end - 1);
     if (p.xstate) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (valid[l]) p.xstate[(size_t)w * p.ldY + t0 + l] = (uint8_t)x[l];
+        for (int l = 0; l < L; ++l) if (t0 + l < T) p.xstate[(size_t)w * p.ldY + t0 + l] = (uint8_t)x[l];
     }
     if (p.x_final) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (valid[l]) p.x_final[(size_t)w * p.ldY + t0 + l] = x[l];
+        for (int l = 0; l < L; ++l) if (t0 + l < T) p.x_final[(size_t)w * p.ldY + t0 + l] = x[l];
     }
     if (p.pif_final && p.sweep_end > p.sweep_begin) {
 #pragma unroll
         for (int l = 0; l < L; ++l)
-            if (valid[l])
+            if (t0 + l < T)
 #pragma unroll
                 for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t0 + l) * K + s] = pf[l][s];
     }
     if (orole >= 0 && orole < NS) {
-        if (p.sumacc) p.sumacc[(size_t)w * NS + orole] = sum_acc;
+        if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;
         if (p.summary && p.final_launch)
             p.summary[(size_t)w * NS + orole] = p.nrun > 0 ? sum_acc / (double)p.nrun : __builtin_nan("");
+    }
+    if (p.sumacc) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) if (tid == k) p.sumacc[(size_t)w * NCK + (NCK - K) + k] = pivot[k];
     }
     if (st) atomicOr(&p.status[w], st);
 }

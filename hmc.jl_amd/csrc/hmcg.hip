@@ -145,8 +145,46 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
     const size_t dyn = sizeof(double) * (size_t)v->NT * v->L;
     if (timing) HIP_TRY(hipEventRecord(g_ctx.ev0, stream));
+#ifdef HMCG_STAMPS
+    const int nwv = v->NT / 64;
+    const size_t ndbg = (size_t)cfg->W * nwv * HMCG_NSTAMP;
+    unsigned long long* ddbg = nullptr;
+    HIP_TRY(hipMalloc((void**)&ddbg, ndbg * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ddbg, 0, ndbg * sizeof(unsigned long long), stream));
+    p.dbg = ddbg;
+#endif
     hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)v->NT), dyn, stream, p);
     HIP_TRY(hipGetLastError());
+#ifdef HMCG_STAMPS
+    {
+        static const char* names[HMCG_NSTAMP] = {"Ba wait", "param draws | shadow jobs", "Bb wait", "theta+ux+pdfs", "local product",
+            "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats"};
+        std::vector<unsigned long long> h(ndbg);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(ddbg);
+        const int nsw = p.sweep_end - p.sweep_begin;
+        fprintf(stderr, "[stamps] K=%d L=%d NT=%d W=%d sweeps=%d: mean cycles per sweep by wave (s_memtime ticks)\n", v->K, v->L, v->NT, cfg->W, nsw);
+        fprintf(stderr, "%-24s", "phase");
+        for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, "   wave%-2d", wv);
+        fprintf(stderr, "\n");
+        std::vector<double> tot(nwv, 0.0);
+        for (int i = 0; i < HMCG_NSTAMP; ++i) {
+            fprintf(stderr, "%-24s", names[i]);
+            for (int wv = 0; wv < nwv; ++wv) {
+                double acc = 0;
+                for (int w = 0; w < cfg->W; ++w) acc += (double)h[((size_t)w * nwv + wv) * HMCG_NSTAMP + i];
+                acc /= (double)cfg->W * (nsw > 0 ? nsw : 1);
+                tot[wv] += acc;
+                fprintf(stderr, " %8.0f", acc);
+            }
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "%-24s", "total");
+        for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, " %8.0f", tot[wv]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (timing) {
         HIP_TRY(hipEventRecord(g_ctx.ev1, stream));
         HIP_TRY(hipEventSynchronize(g_ctx.ev1));
@@ -260,8 +298,8 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
         }
         if (extras->window_ids) { ALLOC(dwid, W); HIP_TRY(hipMemcpyAsync(dwid.p, extras->window_ids, sizeof(uint32_t) * W, hipMemcpyHostToDevice, s)); dex.window_ids = dwid.p; }
         if (extras->sumacc) {
-            ALLOC(dacc, W * NS);
-            if (resume) HIP_TRY(hipMemcpyAsync(dacc.p, extras->sumacc, sizeof(double) * W * NS, hipMemcpyHostToDevice, s));
+            ALLOC(dacc, W * (NS + K));
+            if (resume) HIP_TRY(hipMemcpyAsync(dacc.p, extras->sumacc, sizeof(double) * W * (NS + K), hipMemcpyHostToDevice, s));
             dex.sumacc = dacc.p;
         }
     }
@@ -282,7 +320,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
         D2H(extras->x_final, dxf.p, sizeof(int32_t) * W * ld);
         D2H(extras->pif_final, dpif.p, sizeof(double) * W * ld * K);
         D2H(extras->xstate, dxs.p, W * ld);
-        D2H(extras->sumacc, dacc.p, sizeof(double) * W * NS);
+        D2H(extras->sumacc, dacc.p, sizeof(double) * W * (NS + K));
     }
 #undef D2H
     HIP_TRY(hipStreamSynchronize(s));

@@ -106,7 +106,8 @@ typedef struct hmcg_extras {
     double* pif_final;       /* [W][ldY][K] UNSORTED filtered probabilities pif[t,:] of the last sweep */
     uint8_t* xstate;         /* [W][ldY] chain state for HMCG_FLAG_RESUME: read at start when the flag is
                                 set, written at the end whenever non-NULL (checkpoint) */
-    double* sumacc;          /* [W][3K+K*K+2H] running sums behind `summary` (resume across calls) */
+    double* sumacc;          /* [W][3K+K*K+2H+K] checkpoint block: the running sums behind `summary`, then the K pivots of
+                                the one-pass sufficient statistics (so that a resumed chain is bit-identical) */
     const uint32_t* window_ids; /* [W] explicit RNG stream ids (NULL: window_base + w); lets a sharded /
                                    load-balanced run reproduce the unsharded one window for window */
 } hmcg_extras;
