@@ -93,10 +93,61 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return (double)x * 0x1.0p-53;
 }
 
+// 1/x: hardware reciprocal + one Newton step (<= 1 ulp; within the parity tolerance)
+__device__ __forceinline__ double rcp_fast(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// log(x) for positive normal x (fdlibm-style: x = 2^e * m, m in [sqrt(.5), sqrt(2)), atanh series), < 1 ulp
+__device__ __forceinline__ double log_fast(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * rcp_fast(2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// cos(2*pi*u) for u in [0,1): exact reduction to a quadrant, fdlibm kernels on [-pi/4, pi/4]
+__device__ __forceinline__ double cos2pi_fast(double u)
+{
+    const double k = rint(4.0 * u);                       // 0..4
+    const double r = u - 0.25 * k;                        // exact, |r| <= 1/8
+    const double phi = TWO_PI * r;
+    const double z = phi * phi;
+    const int q = (int)k & 3;
+    // cos kernel
+    const double c = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                     -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                     4.16666666666666019037e-02), -0.5);
+    const double cosv = fma(z, c, 1.0);
+    // sin kernel
+    const double sp = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                      -1.66666666666666324348e-01);
+    const double sinv = fma(phi * z, sp, phi);
+    // cos(k*pi/2 + phi): k=0 cos, 1 -sin, 2 -cos, 3 sin
+    const double v = (q & 1) ? sinv : cosv;
+    return (q == 1 || q == 2) ? -v : v;
+}
+
 __device__ __forceinline__ double box_muller(const uint32_t (&r)[4])
 {
     const double u1 = u53(r[0], r[1]), u2 = u53(r[2], r[3]);
-    return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2);
+    return sqrt(-2.0 * log_fast(1.0 - u1)) * cos2pi_fast(u2);
 }
 
 // Marsaglia-Tsang acceptance for one attempt: returns the variate or a negative number.
@@ -104,7 +155,7 @@ __device__ __forceinline__ double mt_try(double d, double c, double x, double lo
 {
     const double v1 = 1.0 + c * x;
     const double v = v1 * v1 * v1;
-    const bool ok = (v1 > 0.0) && (logu < 0.5 * x * x + d - d * v + d * log(v));
+    const bool ok = (v1 > 0.0) && (logu < 0.5 * x * x + d - d * v + d * log_fast(v1 > 0.0 ? v : 1.0));
     return ok ? d * v : -1.0;
 }
 
@@ -133,13 +184,6 @@ __device__ __forceinline__ double exp_fast(double x)
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
-}
-
-// 1/x: hardware reciprocal + one Newton step (<= 1 ulp; within the parity tolerance)
-__device__ __forceinline__ double rcp_fast(double x)
-{
-    const double r = __builtin_amdgcn_rcp(x);
-    return fma(fma(-x, r, 1.0), r, r);
 }
 
 // ------------------------------------------------------- DPP helpers -----
@@ -177,6 +221,73 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, v);
     return readlane_f64(v, 63);
 }
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// v(lane) + v(lane ^ 32) in every lane (v_permlane32_swap: upper half of one operand <-> lower half of the other)
+__device__ __forceinline__ double xor32_sum(double v)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+// v(lane) + v(lane ^ 16) in every lane (v_permlane16_swap: odd 16-lane rows of one operand <-> even rows of the other)
+__device__ __forceinline__ double xor16_sum(double v)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL>
+__device__ __forceinline__ double quadperm_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-wide sums of 8 per-lane quantities in ~1/3 of the instructions of 8 separate reductions:
+// a butterfly that halves the number of live quantities at each of the first two levels
+// (xor 1, xor 2 inside a quad), then sums the 16 quads (row_shr 4, 8; xor 16; xor 32).
+// On return the lanes with (lane & 12) == 12 hold, in (o0, o1), the totals of slots
+// 4*(lane&1) + (lane&2) + {0, 1}.  Fixed association order: deterministic.
+__device__ __forceinline__ void wave_sum8_transposed(const double (&v)[8], int lane, double& o0, double& o1)
+{
+    const bool p = (lane & 1) != 0, p2 = (lane & 2) != 0;
+    double a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = p ? v[4 + i] : v[i];
+        const double send = p ? v[i] : v[4 + i];
+        a[i] = keep + quadperm_f64<0xB1>(send);          // quad_perm:[1,0,3,2]
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = p2 ? a[2 + i] : a[i];
+        const double send = p2 ? a[i] : a[2 + i];
+        b[i] = keep + quadperm_f64<0x4E>(send);          // quad_perm:[2,3,0,1]
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        b[i] += dpp_f64<DPP_ROW_SHR4, 0xF>(0.0, b[i]);
+        b[i] += dpp_f64<DPP_ROW_SHR8, 0xF>(0.0, b[i]);
+        b[i] = xor16_sum(b[i]);
+        b[i] = xor32_sum(b[i]);
+    }
+    o0 = b[0]; o1 = b[1];
+}
+
+// wave-wide sum of packed non-negative integer fields (no field may overflow into its neighbour);
+// one v_add_u32_dpp per level; the total lands in lane 63
+__device__ __forceinline__ unsigned wave_sum_u32_lane63(unsigned v)
+{
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ double wave_min(double v)
 {
 #pragma unroll
@@ -190,17 +301,28 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
-// Scale every entry by the power of two that brings the largest one into [0.5,1).
-// Exact (no rounding) away from the subnormal range; a zero matrix stays zero.
+// Scale every (non-negative) entry by the power of two that brings the largest one into [0.5,1).
+// Exact (no rounding) away from the subnormal range; a zero matrix stays zero.  The largest
+// exponent is found on the high words as integers (entries are >= 0, so the order is the same).
 template <int N>
 __device__ __forceinline__ void rescale_pow2(double (&q)[N])
 {
-    double m = q[0];
+    unsigned m = (unsigned)__double2hiint(q[0]);
 #pragma unroll
-    for (int i = 1; i < N; ++i) m = fmax(m, q[i]);
-    const int e = (m > 0.0 && m < 1.0e300) ? -ilogb(m) - 1 : 0;
+    for (int i = 1; i < N; ++i) m = max(m, (unsigned)__double2hiint(q[i]));
+    const int be = (int)(m >> 20);                       // biased exponent of the largest entry
+    const int e = (be > 0 && be < 2040) ? 1022 - be : 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) q[i] = ldexp(q[i], e);
+}
+
+// sqrt(x), x > 0 normal: hardware rsq + two Newton steps on the product form (<= 1 ulp)
+__device__ __forceinline__ double sqrt_fast(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);                   // refine 1/sqrt(x)
+    double g = x * r;
+    return fma(fma(-g, g, x), 0.5 * r, g);
 }
 
 // one level of the wave-wide inclusive matrix scan: Q <- (Q of the source lane) * Q
@@ -283,38 +405,35 @@ __device__ inline void matmul_small(double (&out)[K][K], const double (&a)[K][K]
         for (int j = 0; j < K; ++j) out[i][j] = t[i][j];
 }
 
+// (pi' A^h) . mu as pi' (A^h mu): binary exponentiation carrying the vector, log2(h) squarings
 template <int K>
 __device__ inline double forecast_value(const double (&mu)[K], const double (&A)[K][K], const double (&pe)[K], int h)
 {
-    double x[K][K], y[K][K];
+    double M[K][K], v[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i)
+    for (int i = 0; i < K; ++i) {
+        v[i] = mu[i];
 #pragma unroll
-        for (int j = 0; j < K; ++j) { x[i][j] = A[i][j]; y[i][j] = (i == j) ? 1.0 : 0.0; }
-    if (h > 0) {
-        unsigned p = (unsigned)h;
-        int t = __ffs((int)p);          // trailing_zeros + 1
-        p >>= t;
-        while (--t > 0) matmul_small<K>(x, x, x);
+        for (int j = 0; j < K; ++j) M[i][j] = A[i][j];
+    }
+    for (unsigned hh = (unsigned)h; hh != 0; hh >>= 1) {        // h is uniform: scalar loop
+        if (hh & 1u) {
+            double nv[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i)
+            for (int i = 0; i < K; ++i) {
+                double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) y[i][j] = x[i][j];
-        while (p > 0) {
-            t = __ffs((int)p);
-            p >>= t;
-            while (--t >= 0) matmul_small<K>(x, x, x);
-            matmul_small<K>(y, y, x);
+                for (int j = 0; j < K; ++j) acc = fma(M[i][j], v[j], acc);
+                nv[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[i] = nv[i];
         }
+        if (hh > 1u) matmul_small<K>(M, M, M);
     }
     double f = 0.0;
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-        double s1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < K; ++r) s1 += pe[r] * y[r][s];
-        f += s1 * mu[s];
-    }
+    for (int i = 0; i < K; ++i) f = fma(pe[i], v[i], f);
     return f;
 }
 
@@ -340,7 +459,9 @@ template <int K, int L, int NT>
 struct SweepShared {
     static constexpr int NW = NT / 64;
     static constexpr int NCNT = K + K * K;
-    int red_cnt[NW][NCNT];        // per-wave state counts and transition counts
+    static constexpr int NPK = (K * K + 1) / 2;
+    unsigned red_pk[NW][NPK];     // per-wave transition counts C_ij, two 16-bit fields per word (field e = i*K+j)
+    int x_end;                    // X[T-1] of the chain state the statistics describe
     double red_d1[NW][K];         // per-wave sums of (y - pivot_i) by state
     double red_d2[NW][K];         // per-wave sums of (y - pivot_i)^2 by state
     double pivot[K];              // pivots the partial sums above were taken about
@@ -349,7 +470,7 @@ struct SweepShared {
     double wtot[NW][K * K];       // forward scan: wave totals
     double pfirst[NT + 1][K];     // filtered probs at each thread's first step
     uint32_t wmap[NW];            // backward scan: wave totals
-    int xlast;                    // X[T-1]
+    double ulast;                 // the uniform that draws X[T-1]
     int xfirst[NT + 1];           // init only: first state of each thread's chunk
     double bred[NW];              // generic block reductions (init)
     double med[2];
@@ -406,7 +527,7 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 // csrc/Makefile `stamps`); the shipped kernel executes none.  Values leave the kernel only
 // through p.dbg, which no other code reads.
 #ifdef HMCG_STAMPS
-#define HMCG_NSTAMP 14
+#define HMCG_NSTAMP 20
 #define STAMP(i)                                                          \
     do {                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                \
@@ -438,6 +559,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T[w];
     const int t0 = tid * L;
+    const int owner = (T - 1) / L, l_last = (T - 1) % L;   // thread and slot that hold the last time step
     int st = 0;
 
     if (T < 2 || T > NT * L) {           // uniform per block
@@ -538,12 +660,17 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         __syncthreads();                 // sh.ux is reused by the sweeps
     }
 
-    // first state of the next thread's chunk (X at t0+L)
+    // first state of the next thread's chunk (X at t0+L), and X[T-1]
     int xnext = 0;
     sh.xfirst[tid] = x[0];
     if (tid == 0) sh.xfirst[NT] = 0;
+    if (tid == owner) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) if (l == l_last) sh.x_end = x[l];
+    }
     __syncthreads();
     xnext = sh.xfirst[tid + 1];
+    int x_end = sh.x_end;
 
     Rng rng{p.seed_lo, p.seed_hi, p.window_ids ? p.window_ids[w] : p.window_base + (uint32_t)w, 0u};
     const int NS = 3 * K + KK + 2 * p.H;
@@ -552,58 +679,58 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     const int shadow_wave = wave - 1;                  // -1 on wave 0
     constexpr int NSH = NW - 1;
 
-    // normals for the gamma attempts and for mu of sweep `sw` -> sh.rb[sw & 1]
-    auto job_normals = [&](int sw, int l0, int nl) {
+    // State-independent parts of sweep `sw`'s parameter draws -> sh.rb[sw & 1].  One task per lane:
+    //   [0, K)                rho exponentials (site 2), normalised across these K lanes
+    //   [K, K+2NG)            normal of gamma role g>>1, attempt g&1           (block index 2j)
+    //   [K+2NG, 2K+2NG)       normal for mu_i                                  (site 1)
+    //   [2K+2NG, 2K+4NG)      log(1-u) of gamma role, attempt                  (block index 2j+1)
+    // Every task is one Philox block and one log; the normals add sqrt*cos.
+    auto job_prep = [&](int sw) {
         Rng g = rng;
         g.sweep = (uint32_t)sw;
         RngBuf<K>& rb = sh.rb[sw & 1];
-        for (int task = l0; task < 2 * NG + K; task += nl) {
+        constexpr int NTASK = 4 * NG + 2 * K;
+        for (int base = 0; base < NTASK; base += 64) {
+            const int task = base + lane;
+            const bool live = task < NTASK;
+            const bool t_rho = task < K;
+            const bool t_gx = !t_rho && task < K + 2 * NG;
+            const bool t_z = !t_rho && !t_gx && task < 2 * K + 2 * NG;
+            const bool t_gl = !t_rho && !t_gx && !t_z;
+            const int gt = t_gx ? task - K : task - (2 * K + 2 * NG);      // gamma task id for gx / gl
+            const int role = gt >> 1, j = gt & 1;
+            uint32_t site = SITE_RHO, elem = (uint32_t)task, idx = 0;
+            if (t_gx || t_gl) {
+                site = role < K ? SITE_SIG2 : SITE_A;
+                elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
+                idx = 2u * (uint32_t)j + (t_gl ? 1u : 0u);
+            } else if (t_z) {
+                site = SITE_MU; elem = (uint32_t)(task - (K + 2 * NG));
+            }
             uint32_t r[4];
-            if (task < 2 * NG) {
-                const int role = task >> 1, j = task & 1;
-                const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
-                const uint32_t elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
-                g.block(site, elem, 2u * (uint32_t)j, r);
-                rb.x[role][j] = box_muller(r);
-            } else {
-                g.block(SITE_MU, (uint32_t)(task - 2 * NG), 0, r);
-                rb.z[task - 2 * NG] = box_muller(r);
+            g.block(site, elem, idx, r);
+            const double lg = log_fast(1.0 - u53(r[0], r[1]));
+            double val = lg;
+            if (t_gx || t_z) val = sqrt_fast(-2.0 * lg) * cos2pi_fast(u53(r[2], r[3]));   // Box-Muller
+            // rho ~ Dirichlet(ones(K)) (:350-356): K exponentials normalised in element order (lanes 0..K-1 of pass 0)
+            double rs = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) rs += -__shfl(lg, i, 64);
+            if (live) {
+                if (t_rho) rb.rho[task] = -lg * (1.0 / rs);
+                else if (t_gx) rb.x[role][j] = val;
+                else if (t_z) rb.z[task - (K + 2 * NG)] = val;
+                else if (t_gl) rb.lu[role][j] = val;
             }
         }
     };
-    // log(1-u) for the gamma attempts, and the whole rho draw, of sweep `sw`
-    auto job_logs = [&](int sw, int l0, int nl) {
+    static_assert(NW > 2 || 3 * K + KK <= 64 - 2 * HMCG_MAXH, "parameter and forecast output lanes share a wave when NW == 2");
+    // uniforms for the state draws of sweep `sw` (site 4, index t): block b covers t = 2b, 2b+1.
+    // Blocks [b0, b1) are dealt round-robin to the calling wave's lanes.
+    auto job_uniforms = [&](int sw, int b0, int b1) {
         Rng g = rng;
         g.sweep = (uint32_t)sw;
-        RngBuf<K>& rb = sh.rb[sw & 1];
-        for (int task = l0; task < 2 * NG; task += nl) {
-            uint32_t r[4];
-            const int role = task >> 1, j = task & 1;
-            const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
-            const uint32_t elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
-            g.block(site, elem, 2u * (uint32_t)j + 1u, r);
-            rb.lu[role][j] = log(1.0 - u53(r[0], r[1]));
-        }
-        if (l0 == nl - 1) {               // rho ~ Dirichlet(ones(K)) (:350-356): K exponentials, normalised (last lane of the job)
-            double e[K], s = 0.0;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                uint32_t r[4];
-                g.block(SITE_RHO, (uint32_t)i, 0, r);
-                e[i] = -log(1.0 - u53(r[0], r[1]));
-                s += e[i];
-            }
-            const double inv = 1.0 / s;
-#pragma unroll
-            for (int i = 0; i < K; ++i) rb.rho[i] = e[i] * inv;
-        }
-    };
-    // uniforms for the state draws of sweep `sw` (site 4, index t): block b covers t = 2b, 2b+1
-    auto job_uniforms = [&](int sw, int l0, int nl) {
-        Rng g = rng;
-        g.sweep = (uint32_t)sw;
-        const int nblk = (T + 1) >> 1;
-        for (int b = l0; b < nblk; b += nl) {
+        for (int b = b0 + lane; b < b1; b += 64) {
             uint32_t r[4];
             g.block(SITE_X, 0, (uint32_t)b, r);
             sh.ux[2 * b] = u53(r[0], r[1]);
@@ -613,11 +740,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1]); lanes [0,NS) of one wave
     double sum_acc = 0.0;                 // running sum behind `summary` (meaningful on the output lanes only)
-    constexpr int OUT_WAVE = 1;           // the wave that owns the output lanes
-    const int orole = (wave == OUT_WAVE) ? lane : -1;
-    if (orole >= 0 && orole < NS && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
+    constexpr int OUT_WAVE = 1;           // owns the 3K + K^2 parameter output lanes
+    constexpr int FC_WAVE = NW - 1;       // owns the 2H forecast lanes (== OUT_WAVE when NW == 2)
+    const int NP = 3 * K + KK;
+    int orole = -1;
+    if (wave == OUT_WAVE && lane < NP) orole = lane;
+    if (wave == FC_WAVE && lane >= 64 - 2 * HMCG_MAXH && lane - (64 - 2 * HMCG_MAXH) < 2 * p.H) orole = NP + lane - (64 - 2 * HMCG_MAXH);
+    if (orole >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
     auto job_outputs = [&](int sw) {
-        if (sw < p.keep_from || orole < 0 || orole >= NS) return;
+        if (sw < p.keep_from || orole < 0) return;
         const ThetaBuf<K>& th = sh.th[sw & 1];
         const int d = sw - p.keep_from;
         double mu_u[K];
@@ -663,53 +794,100 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         sum_acc += round5(val);
     };
 
+#ifdef HMCG_STAMPS
+    unsigned long long stamp_acc[HMCG_NSTAMP];
+    unsigned long long stamp_prev = 0;
+#endif
     // per-wave partial statistics of the current X: counts, pivoted sums, transitions
+    constexpr int PB = L <= 1 ? 1 : (L <= 3 ? 2 : (L <= 7 ? 3 : (L <= 15 ? 4 : 5)));   // bits holding a per-thread count <= L
+    constexpr int FPW = 32 / PB;                       // per-thread fields per 32-bit word
+    constexpr int NWORD = (KK + FPW - 1) / FPW;
+    constexpr int NPK = Sh::NPK;
+    static_assert(64 * L < 65536, "16-bit wave totals");
     auto publish_stats = [&]() {
+        // ---- transition counts C_ij: per-thread PB-bit fields -> 16-bit fields -> one DPP integer sum per word
+        unsigned acc[NWORD];
 #pragma unroll
-        for (int k = 0; k < K; ++k) if (tid == k) sh.pivot[k] = pivot[k];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            int c = 0;
-            double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const bool hit = (t0 + l < T) && x[l] == i;
-                c += __popcll(__ballot(hit));
-                const double dlt = y[l] - pivot[i];
-                d1 += hit ? dlt : 0.0;
-                d2 += hit ? dlt * dlt : 0.0;
-            }
-            d1 = wave_sum(d1);
-            d2 = wave_sum(d2);
-            if (lane == 0) { sh.red_cnt[wave][i] = c; sh.red_d1[wave][i] = d1; sh.red_d2[wave][i] = d2; }
-        }
-        int code[L];
+        for (int wd = 0; wd < NWORD; ++wd) acc[wd] = 0;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int xn = (l + 1 < L) ? x[(l + 1 < L) ? l + 1 : l] : xnext;
-            code[l] = (t0 + l + 1 < T) ? x[l] * K + xn : -1;
+            const int code = x[l] * K + xn;
+            const bool pv = (t0 + l + 1) < T;
+            if constexpr (NWORD == 1) {
+                acc[0] += pv ? (1u << (PB * code)) : 0u;
+            } else {
+#pragma unroll
+                for (int wd = 0; wd < NWORD; ++wd) {
+                    const int rel = code - wd * FPW;
+                    acc[wd] += (pv && rel >= 0 && rel < FPW) ? (1u << (PB * rel)) : 0u;
+                }
+            }
         }
+        unsigned pk[NPK];
 #pragma unroll
-        for (int e = 0; e < KK; ++e) {
-            int c = 0;
+        for (int d = 0; d < NPK; ++d) {
+            const int e0 = 2 * d, e1 = 2 * d + 1;
+            unsigned v = (acc[e0 / FPW] >> (PB * (e0 % FPW))) & ((1u << PB) - 1u);
+            if (e1 < KK) v |= ((acc[e1 / FPW] >> (PB * (e1 % FPW))) & ((1u << PB) - 1u)) << 16;
+            pk[d] = wave_sum_u32_lane63(v);
+        }
+        // ---- pivoted sums by state: d1_i = sum (y - pivot_i), d2_i = sum (y - pivot_i)^2
+        double d1[K], d2[K];
 #pragma unroll
-            for (int l = 0; l < L; ++l) c += __popcll(__ballot(code[l] == e));
-            if (lane == 0) sh.red_cnt[wave][K + e] = c;
+        for (int i = 0; i < K; ++i) { d1[i] = 0.0; d2[i] = 0.0; }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            double pvt = pivot[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) pvt = (x[l] == k) ? pivot[k] : pvt;
+            const double dl = y[l] - pvt;
+            const int xs = (t0 + l < T) ? x[l] : -1;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const double dm = (xs == i) ? dl : 0.0;
+                d1[i] += dm;
+                d2[i] = fma(dm, dm, d2[i]);
+            }
+        }
+        if constexpr (K <= 4) {
+            double v8[8], o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v8[i] = i < K ? d1[i] : 0.0; v8[4 + i] = i < K ? d2[i] : 0.0; }
+            wave_sum8_transposed(v8, lane, o0, o1);
+            if ((lane & 0x3C) == 12) {                 // lanes 12..15 hold the totals
+                const int i0 = lane & 2, i1 = i0 + 1;  // state index of o0 / o1; lane&1 picks d1 or d2
+                double* dst = (lane & 1) ? &sh.red_d2[wave][0] : &sh.red_d1[wave][0];
+                if (i0 < K) dst[i0] = o0;
+                if (i1 < K) dst[i1] = o1;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) { d1[i] = wave_sum(d1[i]); d2[i] = wave_sum(d2[i]); }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) { sh.red_d1[wave][i] = d1[i]; sh.red_d2[wave][i] = d2[i]; }
+            }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int d = 0; d < NPK; ++d) sh.red_pk[wave][d] = pk[d];
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) sh.pivot[k] = pivot[k];
+            sh.x_end = x_end;
         }
     };
     publish_stats();
 
     // prologue: the first sweep's state-independent RNG parts
-    if (p.sweep_begin < p.sweep_end && shadow_wave == 0) {
-        job_normals(p.sweep_begin, lane, 64);
-        job_logs(p.sweep_begin, lane, 64);
-    }
+    if (p.sweep_begin < p.sweep_end && shadow_wave == 0) job_prep(p.sweep_begin);
 
     double pf[L][K];     // unsorted filtered probabilities of this thread's steps
 #ifdef HMCG_STAMPS
-    unsigned long long stamp_acc[HMCG_NSTAMP];
     for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
-    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
     for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
@@ -724,17 +902,29 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             const int role = lane;
             const bool is_sig = role < K, is_g = role < NG;
             double shape = 1.0, bpar = 1.0, Neff = 0.0, Ssum = 0.0;
-            if (is_g) {
-                int c = 0;
+            // transition count C_e of this lane's A role (e = role - K), summed over the waves' packed words
+            int cT = 0;
+            {
+                const int e = (role >= K && is_g) ? role - K : 0;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) c += sh.red_cnt[ww][role];      // N_i for sig roles, C_ij for A roles
+                for (int ww = 0; ww < NW; ++ww) cT += (int)((sh.red_pk[ww][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+            }
+            // N_i = sum_j C_ij + [X[T-1] == i]: row sums through the A lanes
+            int rowsum = 0;
+            {
+                const int i = is_sig ? role : 0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) rowsum += __shfl(cT, K + i * K + j, 64);
+            }
+            if (is_g) {
+                const int c = is_sig ? rowsum + ((sh.x_end == role) ? 1 : 0) : cT;
                 if (is_sig) {
                     double d1 = 0.0, d2 = 0.0;
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) { d1 += sh.red_d1[ww][role]; d2 += sh.red_d2[ww][role]; }
                     const double piv = sh.pivot[role];
                     Neff = (double)c;
-                    const double rn = c > 0 ? 1.0 / Neff : 0.0;
+                    const double rn = c > 0 ? rcp_fast(Neff) : 0.0;
                     const double ybar = c > 0 ? piv + d1 * rn : 0.0;             // :259-265, :282-288
                     const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;  // sum (y-ybar)^2 (:291-294)
                     Ssum = piv * Neff + d1;                                      // sum of y in the state
@@ -754,11 +944,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                     // Gamma(1) = exponential of block index 0: only for a never-visited state pair; inline
                     uint32_t r[4];
                     rng.block(site, elem, 0, r);
-                    val = -log(1.0 - u53(r[0], r[1]));
+                    val = -log_fast(1.0 - u53(r[0], r[1]));
                 } else {
                     const double a = shape < 1.0 ? shape + 1.0 : shape;
                     const double dd = a - 1.0 / 3.0;
-                    const double cc = 1.0 / sqrt(9.0 * dd);
+                    const double cc = rcp_fast(3.0 * sqrt_fast(dd));
                     val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0]);
                     if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1]);
                     if (val < 0.0) {
@@ -769,7 +959,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                             rng.block(site, elem, 2u * (uint32_t)j, r);
                             const double xx = box_muller(r);
                             rng.block(site, elem, 2u * (uint32_t)j + 1u, r);
-                            val = mt_try(dd, cc, xx, log(1.0 - u53(r[0], r[1])));
+                            val = mt_try(dd, cc, xx, log_fast(1.0 - u53(r[0], r[1])));
                         }
                         if (val < 0.0) { val = dd; st |= HMCG_ST_GAMMA_CAP; }
                     }
@@ -786,29 +976,47 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
             for (int j = 0; j < K; ++j) gs += __shfl(val, gbase + j, 64);
             if (is_sig) {
-                const double sig2 = 1.0 / (val * (1.0 / bpar));                  // :320 InverseGamma(a,b)
-                const double m = (Ssum + p.nu * xi) / (Neff + p.nu);             // :331
-                const double sdev = sqrt(sig2 / (Neff + p.nu));                  // :332
+                const double sig2 = bpar * rcp_fast(val);                        // :320 InverseGamma(a,b) = b / Gamma(a,1)
+                const double rnn = rcp_fast(Neff + p.nu);
+                const double m = (Ssum + p.nu * xi) * rnn;                       // :331
+                const double sd = sqrt_fast(sig2);                               // :381
+                const double sdev = sd * sqrt_fast(rnn);                         // :332 sqrt(sig2/(Neff+nu))
                 const double mu = m + sdev * rb.z[role];                         // :334
-                const double sd = sqrt(sig2);                                    // :381
+                const double isd = rcp_fast(sd);
                 th.mu[role] = mu; th.sig2[role] = sig2;
-                th.isd[role] = 1.0 / sd; th.coef[role] = INVSQRT2PI / sd;
+                th.isd[role] = isd; th.coef[role] = INVSQRT2PI * isd;
                 th.rho[role] = rb.rho[role];                                     // :355
             } else if (is_g) {
                 const int e = role - K;
-                th.A[e / K][e % K] = val * (1.0 / gs);
+                th.A[e / K][e % K] = val * rcp_fast(gs);
             }
         } else {
             // ---- shadow of the parameter draws ----
-            if (shadow_wave == 0 && sweep > p.sweep_begin) job_outputs(sweep - 1);
+            // Work list: parameter outputs of the previous sweep (wave 1), its forecasts (last wave), the
+            // next sweep's RNG preparation (wave 1), and this sweep's (T+1)/2 Philox blocks of state-draw
+            // uniforms, dealt to the shadow waves in proportion to what else they carry.
+            const int nblk = (T + 1) >> 1;
+            if (sweep > p.sweep_begin) job_outputs(sweep - 1);
+            STAMP(14);
             if (NSH >= 3) {
-                // wave 1: outputs; waves 2..: the RNG preparation and the uniforms
-                if (shadow_wave == 1 && sweep + 1 < p.sweep_end) job_normals(sweep + 1, lane, 64);
-                if (shadow_wave == 2 && sweep + 1 < p.sweep_end) job_logs(sweep + 1, lane, 64);
-                if (shadow_wave >= 1) job_uniforms(sweep, (shadow_wave - 1) * 64 + lane, (NSH - 1) * 64);
+                // shares in 1/16ths: wave 1 (outputs + prep) 2, last wave (forecast) 5, middle waves the rest
+                const int mid = NSH - 2;
+                const int c1 = (nblk * 2) / 16, cl = (nblk * 5) / 16;
+                const int per_mid = (nblk - c1 - cl + mid - 1) / mid;
+                if (shadow_wave == 0) {
+                    if (sweep + 1 < p.sweep_end) job_prep(sweep + 1);
+                    STAMP(15);
+                    job_uniforms(sweep, 0, c1);
+                } else if (shadow_wave == NSH - 1) {
+                    job_uniforms(sweep, c1, c1 + cl);
+                } else {
+                    const int b0 = c1 + cl + (shadow_wave - 1) * per_mid;
+                    job_uniforms(sweep, b0, min(b0 + per_mid, nblk));
+                }
             } else {
-                if (shadow_wave == NSH - 1 && sweep + 1 < p.sweep_end) { job_normals(sweep + 1, lane, 64); job_logs(sweep + 1, lane, 64); }
-                job_uniforms(sweep, shadow_wave * 64 + lane, NSH * 64);
+                if (shadow_wave == 0 && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
+                const int per = (nblk + NSH - 1) / NSH;
+                job_uniforms(sweep, shadow_wave * per, min((shadow_wave + 1) * per, nblk));
             }
         }
         STAMP(1);
@@ -831,31 +1039,33 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         double f[L][K];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            double fm = 0.0;
+            unsigned hm = 0;
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 const double z = (y[l] - mu[s]) * isd[s];
                 f[l][s] = exp_fast(-0.5 * (z * z)) * coef[s];
-                fm = fmax(fm, f[l][s]);
+                hm = max(hm, (unsigned)__double2hiint(f[l][s]));
             }
-            if (!(fm >= 1e-300)) {
+            if (hm < 0x01A56E1Fu) {                  // largest pdf < 1e-300 (high word of 1e-300 is 0x01A56E1F)
                 // every pdf underflowed: treat the observation as missing (f = 1) and flag the window
                 if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
                 for (int s = 0; s < K; ++s) f[l][s] = 1.0;
             } else {
-                const int e = -ilogb(fm) - 1;        // exact power-of-two scaling of the step
+                const int e = 1022 - (int)(hm >> 20);   // exact power-of-two scaling of the step: largest pdf into [0.5,1)
 #pragma unroll
                 for (int s = 0; s < K; ++s) f[l][s] = ldexp(f[l][s], e);
             }
         }
         STAMP(3);
-        // local product Q = M_{t0} ... M_{t0+L-1} (identity for padded steps)
+        // local product Q = M_{t0} ... M_{t0+L-1}
+        // (padded steps t >= T take part with y = 0: everything they influence lies at or beyond T,
+        //  where no result is consumed -- prefixes only flow forward in time)
         double Q[KK];
 #pragma unroll
         for (int r = 0; r < K; ++r)
 #pragma unroll
-            for (int s = 0; s < K; ++s) Q[r * K + s] = (t0 < T) ? A[r][s] * f[0][s] : ((r == s) ? 1.0 : 0.0);
+            for (int s = 0; s < K; ++s) Q[r * K + s] = A[r][s] * f[0][s];
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             double N[KK];
@@ -868,9 +1078,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                     for (int k = 1; k < K; ++k) acc = fma(Q[r * K + k], A[k][s], acc);
                     N[r * K + s] = acc * f[l][s];
                 }
-            const bool v = (t0 + l) < T;
 #pragma unroll
-            for (int i = 0; i < KK; ++i) Q[i] = v ? N[i] : Q[i];
+            for (int i = 0; i < KK; ++i) Q[i] = N[i];
         }
         rescale_pow2<KK>(Q);
         STAMP(4);
@@ -906,7 +1115,6 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
                 nv[s] = acc;
             }
-            rescale_pow2<K>(nv);
 #pragma unroll
             for (int s = 0; s < K; ++s) av[s] = (ww < wave) ? nv[s] : av[s];
         }
@@ -927,61 +1135,55 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         // replay the normalised recursion over this thread's steps (:413-432)
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if (t0 + l < T) {
-                double nv[K], total = 0.0;
+            double nv[K], total = 0.0;
 #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    double acc = av[0] * A[0][s];
+            for (int s = 0; s < K; ++s) {
+                double acc = av[0] * A[0][s];
 #pragma unroll
-                    for (int r = 1; r < K; ++r) acc = fma(av[r], A[r][s], acc);
-                    nv[s] = acc * f[l][s];
-                    total += nv[s];
-                }
-                if (!(total > 0.0)) {
-                    st |= HMCG_ST_EMIS_UNDERFLOW;
-#pragma unroll
-                    for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
-                    total = 1.0;
-                }
-                const double inv = rcp_fast(total);
-#pragma unroll
-                for (int s = 0; s < K; ++s) av[s] = nv[s] * inv;
+                for (int r = 1; r < K; ++r) acc = fma(av[r], A[r][s], acc);
+                nv[s] = acc * f[l][s];
+                total += nv[s];
             }
+            if (!(total > 0.0)) {                   // not reachable with finite positive parameters; kept as a guard
+                if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
-            for (int s = 0; s < K; ++s) pf[l][s] = av[s];
+                for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
+                total = 1.0;
+            }
+            const double inv = rcp_fast(total);
+#pragma unroll
+            for (int s = 0; s < K; ++s) { av[s] = nv[s] * inv; pf[l][s] = av[s]; }
         }
 #pragma unroll
         for (int s = 0; s < K; ++s) sh.pfirst[tid][s] = pf[0][s];
-        // owner of the last step: pib[end,:] and the draw of X[T-1] in SORTED labels (:464)
-        if (t0 <= T - 1 && T - 1 < t0 + L) {
-            double pe[K];
-            double ulast = 0.0;
+        // owner of the last step publishes pif[T-1,:] (unsorted) and its uniform; X[T-1] itself (sorted
+        // labels, :464) is then drawn redundantly by every thread after the barrier (no divergent tail)
+        if (tid == owner) {
 #pragma unroll
             for (int l = 0; l < L; ++l)
-                if (t0 + l == T - 1) {
-                    ulast = ux[l];
+                if (l == l_last) {
 #pragma unroll
-                    for (int s = 0; s < K; ++s) pe[s] = pf[l][s];
+                    for (int s = 0; s < K; ++s) th.pi_end[s] = pf[l][s];
+                    sh.ulast = ux[l];
                 }
-            double cp = 0.0;
-            int idx = 0;
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                double pq = 0.0;
-#pragma unroll
-                for (int s = 0; s < K; ++s) pq = (order[q] == s) ? pe[s] : pq;
-                cp += pq;
-                if (q < K - 1) idx += (cp <= ulast) ? 1 : 0;
-            }
-#pragma unroll
-            for (int s = 0; s < K; ++s) th.pi_end[s] = pe[s];
-            sh.xlast = idx;
         }
         STAMP(7);
         __syncthreads();                                                     // Bd
         STAMP(8);
         // ---- backward sampling (:459-484) as a suffix scan of state maps ----
-        const int xlast = sh.xlast;
+        int xlast = 0;
+        {
+            const double ulast = sh.ulast;
+            double cp = 0.0;
+#pragma unroll
+            for (int q = 0; q < K - 1; ++q) {
+                double pq = 0.0;
+#pragma unroll
+                for (int s = 0; s < K; ++s) pq = (order[q] == s) ? th.pi_end[s] : pq;
+                cp += pq;
+                xlast += (cp <= ulast) ? 1 : 0;
+            }
+        }
         double pfn_last[K];
 #pragma unroll
         for (int s = 0; s < K; ++s) pfn_last[s] = sh.pfirst[(tid + 1 < NT) ? tid + 1 : tid][s];
@@ -993,22 +1195,23 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             uint32_t m = 0;
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                // p[r] = Pf[t+1,r,s] is proportional to pif[t,r] * A[r,s]; its sum over r equals
-                // the unsorted pif[t+1,s], which drives the eps() guard (:472, quirk 7)
+                // p[r] = Pf[t+1,r,s] is proportional to pif[t,r] * A[r,s]; its sum over r equals the
+                // unsorted pif[t+1,s], which drives the eps() guard (:472, quirk 7).  A failed guard
+                // (common for states far from y[t+1]) selects the uniform 1/K law (:476-480).
                 const double guard = (l + 1 < L) ? pf[(l + 1 < L) ? l + 1 : l][s] : pfn_last[s];
                 const bool gok = guard > EPS64;
-                double tot = 0.0;
+                double tot = 0.0, ucum = 0.0;
+                int idx = 0;
                 double cum[K];
 #pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    const double wr = gok ? pf[l][r] * A[r][s] : 1.0 / K;       // uniform 1/K fallback (:476-480)
-                    tot += wr;
-                    cum[r] = tot;
-                }
+                for (int r = 0; r < K; ++r) { tot = fma(pf[l][r], A[r][s], tot); cum[r] = tot; }
                 const double thr = gok ? ux[l] * tot : ux[l];
-                int idx = 0;
 #pragma unroll
-                for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
+                for (int r = 0; r < K - 1; ++r) {
+                    ucum += 1.0 / K;
+                    const double c = gok ? cum[r] : ucum;
+                    idx += (c <= thr) ? 1 : 0;
+                }
                 m |= (uint32_t)idx << (4 * s);
             }
             m = (t == T - 1) ? map_const<K>(xlast) : (t > T - 1 ? map_identity<K>() : m);
@@ -1021,7 +1224,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t O = __shfl_down(Hm, d, 64);
-            if (lane + d < 64) Hm = map_compose<K>(Hm, O);
+            const uint32_t C = map_compose<K>(Hm, O);
+            Hm = (lane + d < 64) ? C : Hm;
         }
         if (lane == 0) sh.wmap[wave] = Hm;
         STAMP(10);
@@ -1035,6 +1239,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         const uint32_t Sfx = map_compose<K>(Hx, Rw);   // everything after this thread's chunk
         int sin = map_apply(Sfx, 0);                   // constant map below T-1: evaluate anywhere
         xnext = sin;
+        x_end = xlast;
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
             if (t0 + l < T) { sin = map_apply(gmap[l], sin); x[l] = sin; }
@@ -1069,7 +1274,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
                 for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t0 + l) * K + s] = pf[l][s];
     }
-    if (orole >= 0 && orole < NS) {
+    if (orole >= 0) {
         if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;
         if (p.summary && p.final_launch)
             p.summary[(size_t)w * NS + orole] = p.nrun > 0 ? sum_acc / (double)p.nrun : __builtin_nan("");

@@ -158,7 +158,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
 #ifdef HMCG_STAMPS
     {
         static const char* names[HMCG_NSTAMP] = {"Ba wait", "param draws | shadow jobs", "Bb wait", "theta+ux+pdfs", "local product",
-            "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats"};
+            "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats", "  (shadow: outputs)", "  (shadow: prep)", "  (stats: accumulate+N ballots)", "  (stats: wave sums)", "  (stats: pair ballots)", "unused"};
         std::vector<unsigned long long> h(ndbg);
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
