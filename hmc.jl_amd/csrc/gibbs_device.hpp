@@ -730,15 +730,20 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     auto job_uniforms = [&](int sw, int b0, int b1) {
         Rng g = rng;
         g.sweep = (uint32_t)sw;
-        for (int b = b0 + lane; b < b1; b += 64) {
-            uint32_t r[4];
+        for (int b = b0 + lane; b < b1; b += 128) {       // two independent blocks per trip (ILP across the mul chains)
+            const int bb = b + 64;
+            uint32_t r[4], q[4];
             g.block(SITE_X, 0, (uint32_t)b, r);
+            g.block(SITE_X, 0, (uint32_t)bb, q);
             sh.ux[2 * b] = u53(r[0], r[1]);
             if (2 * b + 1 < NT * L) sh.ux[2 * b + 1] = u53(r[2], r[3]);
+            if (bb < b1) {
+                sh.ux[2 * bb] = u53(q[0], q[1]);
+                if (2 * bb + 1 < NT * L) sh.ux[2 * bb + 1] = u53(q[2], q[3]);
+            }
         }
     };
 
-    // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1]); lanes [0,NS) of one wave
     double sum_acc = 0.0;                 // running sum behind `summary` (meaningful on the output lanes only)
     constexpr int OUT_WAVE = 1;           // owns the 3K + K^2 parameter output lanes
     constexpr int FC_WAVE = NW - 1;       // owns the 2H forecast lanes (== OUT_WAVE when NW == 2)
@@ -747,50 +752,63 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     if (wave == OUT_WAVE && lane < NP) orole = lane;
     if (wave == FC_WAVE && lane >= 64 - 2 * HMCG_MAXH && lane - (64 - 2 * HMCG_MAXH) < 2 * p.H) orole = NP + lane - (64 - 2 * HMCG_MAXH);
     if (orole >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
+    // per-lane constants of the output role (decoded once per launch)
+    double* out_base = nullptr;           // element (d=0) of this lane's output column
+    int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0;
+    double fc_yr = 0.0;
+    {
+        const size_t nrun = (size_t)p.nrun;
+        if (orole >= 0 && orole < 3 * K) {
+            o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
+            double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
+            if (base) out_base = base + nrun * ((size_t)o_q + (size_t)K * w);
+        } else if (orole >= 3 * K && orole < NP) {
+            const int e = orole - 3 * K;                   // column-major: e = i + K*j (src/Hmc.jl:745)
+            o_which = 3; o_i = e % K; o_j = e / K;
+            if (p.A) out_base = p.A + nrun * ((size_t)e + (size_t)KK * w);
+        } else if (orole >= NP) {
+            const int e = orole - NP;                      // 2h + {0: forecast, 1: error}
+            o_which = 4 + (e & 1);
+            fc_h = p.horizons[e >> 1];
+            fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (e >> 1)] : __builtin_nan("");
+            if (p.fcast) out_base = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w);
+        }
+    }
+    // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
     auto job_outputs = [&](int sw) {
         if (sw < p.keep_from || orole < 0) return;
         const ThetaBuf<K>& th = sh.th[sw & 1];
         const int d = sw - p.keep_from;
-        double mu_u[K];
-        int order[K];
+        double val;
+        if (o_which >= 4) {
+            // forecast (src/Hmc.jl:658-667).  (pi' A^h) . mu is invariant under the label permutation, so the
+            // unsorted parameters are used as they are.
+            double mu_u[K], pe_u[K], A_u[K][K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) mu_u[i] = th.mu[i];
-        sort_order<K>(mu_u, order);
-        const size_t nrun = (size_t)p.nrun;
-        double val = 0.0;
-        double* dst = nullptr;
-        if (orole < 3 * K) {
-            const int q = orole % K, which = orole / K;     // 0 mu, 1 sig2, 2 pi_end, sorted position q
-            int src = 0;
+            for (int i = 0; i < K; ++i) {
+                mu_u[i] = th.mu[i]; pe_u[i] = th.pi_end[i];
 #pragma unroll
-            for (int qq = 0; qq < K; ++qq) src = (qq == q) ? order[qq] : src;
-            val = which == 0 ? th.mu[src] : (which == 1 ? th.sig2[src] : th.pi_end[src]);
-            double* base = which == 0 ? p.mu : (which == 1 ? p.sig2 : p.pi_end);
-            if (base) dst = base + nrun * ((size_t)q + (size_t)K * w) + d;
-        } else if (orole < 3 * K + KK) {
-            const int e = orole - 3 * K;                    // column-major: e = i + K*j (src/Hmc.jl:745)
-            const int i0 = e % K, j0 = e / K;
+                for (int j = 0; j < K; ++j) A_u[i][j] = th.A[i][j];
+            }
+            const double fv = forecast_value<K>(mu_u, A_u, pe_u, fc_h);
+            val = (o_which == 5) ? fv - fc_yr : fv;
+        } else {
+            double mu_u[K];
+            int order[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) mu_u[i] = th.mu[i];
+            sort_order<K>(mu_u, order);
             int si = 0, sj = 0;
 #pragma unroll
-            for (int qq = 0; qq < K; ++qq) { si = (qq == i0) ? order[qq] : si; sj = (qq == j0) ? order[qq] : sj; }
-            val = th.A[si][sj];                             // A[i1,j1] = Atmp[order[i1], order[j1]] (:506-511)
-            if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + d;
-        } else {
-            const int e = orole - 3 * K - KK;               // 2h + {0: forecast, 1: error}
-            const int h = e >> 1;
-            double smu[K], spe[K], sA[K][K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) { smu[q] = th.mu[order[q]]; spe[q] = th.pi_end[order[q]]; }
-#pragma unroll
-            for (int q = 0; q < K; ++q)
-#pragma unroll
-                for (int q2 = 0; q2 < K; ++q2) sA[q][q2] = th.A[order[q]][order[q2]];
-            const double fv = forecast_value<K>(smu, sA, spe, p.horizons[h]);
-            const double yr = p.yreal ? p.yreal[(size_t)w * p.H + h] : __builtin_nan("");
-            val = (e & 1) ? fv - yr : fv;
-            if (p.fcast) dst = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w) + d;
+            for (int qq = 0; qq < K; ++qq) {
+                si = (qq == (o_which == 3 ? o_i : o_q)) ? order[qq] : si;
+                sj = (qq == o_j) ? order[qq] : sj;
+            }
+            // sorted views: mu[order[q]], sig2[order[q]], pib_end[order[q]], A[order[i], order[j]] (:502-513)
+            const double* src = o_which == 0 ? &th.mu[0] : (o_which == 1 ? &th.sig2[0] : (o_which == 2 ? &th.pi_end[0] : &th.A[0][0]));
+            val = src[o_which == 3 ? si * K + sj : si];
         }
-        if (dst) *dst = val;
+        if (out_base) out_base[d] = val;
         sum_acc += round5(val);
     };
 
