@@ -1017,20 +1017,28 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             if (sweep > p.sweep_begin) job_outputs(sweep - 1);
             STAMP(14);
             if (NSH >= 3) {
-                // shares in 1/16ths: wave 1 (outputs + prep) 2, last wave (forecast) 5, middle waves the rest
-                const int mid = NSH - 2;
-                const int c1 = (nblk * 2) / 16, cl = (nblk * 5) / 16;
-                const int per_mid = (nblk - c1 - cl + mid - 1) / mid;
-                if (shadow_wave == 0) {
-                    if (sweep + 1 < p.sweep_end) job_prep(sweep + 1);
-                    STAMP(15);
-                    job_uniforms(sweep, 0, c1);
-                } else if (shadow_wave == NSH - 1) {
-                    job_uniforms(sweep, c1, c1 + cl);
-                } else {
-                    const int b0 = c1 + cl + (shadow_wave - 1) * per_mid;
-                    job_uniforms(sweep, b0, min(b0 + per_mid, nblk));
+                // fixed jobs: wave 1 parameter outputs (~1.0k cycles), wave 2 RNG preparation (~1.5k), last
+                // wave forecasts (~2.1k); the Philox blocks (~0.5k cycles per lane-block) fill them up to an
+                // even finish: shares in 1/16ths = 8 (wave 1), 5 (wave 2), 3 (last), any further waves take
+                // equal parts of wave 1's and wave 2's share
+                const int extra = NSH - 3;
+                const int c_last = (nblk * 3) / 16;
+                const int rest = nblk - c_last;
+                // weights 8 : 5 : (6.5 each for extra waves, which carry no fixed job)
+                const int den = 2 * (8 + 5) + 13 * extra;
+                const int c0 = (rest * 16) / den, c1 = (rest * 10) / den;
+                int b0, b1;
+                if (shadow_wave == 0) { b0 = 0; b1 = c0; }
+                else if (shadow_wave == 1) { b0 = c0; b1 = extra > 0 ? c0 + c1 : rest; }   // no gap when no extra waves
+                else if (shadow_wave == NSH - 1) { b0 = rest; b1 = nblk; }
+                else {
+                    const int per = extra > 0 ? (rest - c0 - c1 + extra - 1) / extra : 0;
+                    b0 = c0 + c1 + (shadow_wave - 2) * per;
+                    b1 = min(b0 + per, rest);
                 }
+                if (shadow_wave == 1 && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
+                STAMP(15);
+                job_uniforms(sweep, b0, b1);
             } else {
                 if (shadow_wave == 0 && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
                 const int per = (nblk + NSH - 1) / NSH;
