@@ -1,0 +1,201 @@
+# Hmc.jl -- Julia host module over libhmcgibbs.so (C ABI: include/hmcg.h).
+#
+# Drop-in for the data-parallel hot path of joe5saia/Hmc.jl: the same unexported names the
+# reference's drivers call (code/run_hmm.jl:77,95,119,120) -- Hmc.estopt, Hmc.estimatemodel,
+# Hmc.saveresults, Hmc.startdate/enddate/makey/yobs, Hmc.forecast, makedate -- plus the additive
+# batched entry Hmc.estimatewindows.  All sampling happens in hand-written HIP kernels behind a
+# thin ccall; this file is plumbing (argument marshalling, Julia-layout result arrays, CSV).
+#
+# STATUS: written against Julia >= 1.6 and NOT EXECUTED -- neither the build image nor the GPU box
+# has a `julia` binary.  The tested host layer with the same surface is hmc.jl_amd/hmc.py; the C ABI
+# it shares with this file is what the parity tests exercise.
+#
+# Reference lines mirrored: estopt src/Hmc.jl:17-73, accessors :85-107, makedate :573-582,
+# forecast :658-667, basicsave/saveresults :707-748, estimatemodel :850-865.
+module Hmc
+
+using Dates
+using Printf
+using LinearAlgebra
+
+export makedate
+
+const LIBHMCG = get(ENV, "HMCG_LIBRARY", joinpath(@__DIR__, "..", "csrc", "libhmcgibbs.so"))
+const HMCG_MAXH = 8
+
+# ---- C structs (include/hmcg.h) ------------------------------------------------------------
+struct hmcg_config
+    struct_size::Int32
+    W::Int32
+    K::Int32
+    ldY::Int32
+    max_T::Int32
+    burnin::Int32
+    nrun::Int32
+    H::Int32
+    horizons::NTuple{HMCG_MAXH,Int32}
+    seed::UInt64
+    window_base::UInt32
+    device::Int32
+    flags::Int32
+    threads_per_window::Int32
+    sweep_base::Int32
+    sweep_count::Int32
+    alpha::Float64
+    nu::Float64
+end
+
+last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))
+device_count() = Int(ccall((:hmcg_device_count, LIBHMCG), Cint, ()))
+
+# ---- options (field names and keyword defaults of the reference struct) ---------------------
+mutable struct estopt
+    rawdata::Vector{Float64}
+    dates::Vector{Date}
+    sampleRange::AbstractVector{Int}
+    signalRange::AbstractVector{Int}
+    signalSave::AbstractVector{Int}
+    obsRange::AbstractVector{Int}
+    endIndex::Int
+    horizons::Vector{Int}
+    D::Int
+    burnin::Int
+    Nrun::Int
+    signalburnin::Int
+    signalNrun::Int
+    noise::Float64
+    noiseSamples::Int
+    σsignal::Float64
+    series::String
+    seed::Int
+    function estopt(rawdata, dates; sampleRange=1:121, signalRange=2:1, signalSave=2:1, endIndex=121,
+                    horizons=[12], D=3, burnin=1_000, Nrun=1_000, signalburnin=1_000, signalNrun=1_000,
+                    noise=0.0, noiseSamples=1, σsignal=0.0, series="offical", seed=1234)
+        issubset(signalRange, sampleRange) || @error "signalRange is not a subset of sampleRange"
+        issubset(signalSave, signalRange) || @error "signalSave is not a subset of signalRange"
+        new(Vector{Float64}(rawdata), Vector{Date}(dates), sampleRange, signalRange, signalSave,
+            setdiff(sampleRange, signalRange), endIndex, collect(Int, horizons), D, burnin, Nrun,
+            signalburnin, signalNrun, noise, noiseSamples, σsignal, series, seed)
+    end
+end
+
+update_itators!(opt::estopt) = (opt.obsRange = setdiff(opt.sampleRange, opt.signalRange); nothing)
+makey(x::estopt) = x.rawdata[x.sampleRange]
+enddate(x::estopt, extra=0) = x.dates[x.endIndex + extra]
+startdate(x::estopt) = x.dates[first(x.sampleRange)]
+yobs(x::estopt, index) = x.rawdata[index]
+yend(x::estopt, extra=0) = x.rawdata[x.endIndex + extra]
+
+function makedate(x)
+    y = Int(x)
+    Dates.Date(y ÷ 12 + 1960, mod(y, 12) + 1)
+end
+
+function forecast(μ, A, πb, horizon, Yreal)
+    f = dot(vec(πb' * A^horizon), μ)
+    return f, f - Yreal
+end
+
+# ---- the ccall ---------------------------------------------------------------------------
+function _check_live(opt::estopt)
+    isempty(opt.signalRange) || error("signal ranges (estimatesignals!) are outside the accelerated path")
+    (first(opt.sampleRange) == 1 && collect(opt.sampleRange) == collect(1:last(opt.sampleRange))) ||
+        error("sampleRange must be 1:N (src/Hmc.jl indexes window-relative arrays with absolute indices)")
+end
+
+_yreal(opt::estopt) = [opt.endIndex + h <= length(opt.rawdata) ? opt.rawdata[opt.endIndex + h] : NaN for h in opt.horizons]
+
+"""
+    estimatewindows(opts::Vector{estopt}; device=0, keepdraws=true, window_ids=nothing)
+
+One GPU call for many windows (all must share D, burnin, Nrun, horizons, seed).  Returns
+`(samples::Vector{NamedTuple}, summary::Matrix{Float64}, status::Vector{Int32})`; `summary[:, w]` holds the
+means of the 5-digit-rounded draws in the order mu | sigma | pib_end | A(:) | forecasts.
+"""
+function estimatewindows(opts::Vector{estopt}; device::Integer=0, keepdraws::Bool=true, window_ids=nothing)
+    foreach(_check_live, opts)
+    o = opts[1]
+    W = length(opts); K = o.D; H = length(o.horizons); nrun = o.Nrun
+    Ts = Int32[length(x.sampleRange) for x in opts]
+    ldY = Int(maximum(Ts))
+    Y = zeros(Float64, ldY, W)                       # column w = window w  (C: Y[w][t])
+    yreal = zeros(Float64, max(H, 1), W)
+    for (w, x) in enumerate(opts)
+        Y[1:Ts[w], w] = makey(x)
+        H > 0 && (yreal[1:H, w] = _yreal(x))
+    end
+    hz = ntuple(i -> i <= H ? Int32(o.horizons[i]) : Int32(0), HMCG_MAXH)
+    cfg = Ref(hmcg_config(Int32(sizeof(hmcg_config)), W, K, ldY, Int32(maximum(Ts)), o.burnin, nrun, H, hz,
+                          UInt64(o.seed), UInt32(0), Int32(device), Int32(0), Int32(0), Int32(0), Int32(0), 0.0, 0.0))
+    NS = 3K + K * K + 2H
+    μ = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
+    σ = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
+    A = keepdraws ? Array{Float64}(undef, nrun, K, K, W) : Float64[]
+    πe = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
+    fc = keepdraws ? Array{Float64}(undef, nrun, 2H, W) : Float64[]
+    summary = Array{Float64}(undef, NS, W)
+    status = zeros(Int32, W)
+    p(a) = isempty(a) ? Ptr{Float64}(C_NULL) : pointer(a)
+    # window_ids would travel in hmcg_extras; omitted here (window w uses RNG stream w)
+    window_ids === nothing || error("window_ids: pass through hmcg_extras (not wired in this host file yet)")
+    rc = GC.@preserve Y Ts yreal μ σ A πe fc summary status begin
+        ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
+              (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Cvoid}, Ptr{Cvoid}),
+              cfg, Y, Ts, H > 0 ? pointer(yreal) : Ptr{Float64}(C_NULL), p(μ), p(σ), p(A), p(πe), p(fc),
+              summary, status, C_NULL, C_NULL)
+    end
+    rc == 0 || error("libhmcgibbs rc=$rc: $(last_error())")
+    samples = NamedTuple[]
+    if keepdraws
+        for (w, x) in enumerate(opts)
+            push!(samples, (μ = μ[:, :, w], σ = σ[:, :, w],
+                            πb = reshape(πe[:, :, w], nrun, 1, K),   # only the last time step is produced (src/Hmc.jl:744,861)
+                            A = A[:, :, :, w], forecasts = fc[:, :, w], obsdates = fill(enddate(x), nrun)))
+        end
+    end
+    return samples, summary, status
+end
+
+"""
+    estimatemodel(opt) -> (μ, σ, πb, A, forecasts, obsdates)      (src/Hmc.jl:850-865)
+
+`πb` has size (Nrun, 1, D): only `πb[:, end, :]` exists, which is all `saveresults` and `forecast` read.
+"""
+estimatemodel(opt::estopt; device::Integer=0) = estimatewindows([opt]; device=device)[1][1]
+
+# ---- CSV output (layout of src/Hmc.jl:707-748) ---------------------------------------------
+function _fmt(x::Float64)
+    isnan(x) && return "NaN"
+    x == trunc(x) && abs(x) < 1e15 && return string(Int64(x))
+    return repr(x)            # shortest round-trip digits; CSV.jl 0.5.16's integer-mantissa form for |x| < 1e-4
+                              # (e.g. 24e-11) is reproduced only by the Python host layer so far
+end
+
+function basicsave(data, dates, fname, dataheader; precision=5)
+    open(fname, "w") do io
+        println(io, join(vcat(["date"], String.(dataheader)), ","))
+        for i in 1:size(data, 1)
+            println(io, join(vcat([string(dates[i])], [_fmt(round(Float64(v); digits=precision)) for v in data[i, :]]), ","))
+        end
+    end
+end
+
+function saveresults(samples, opt, dir; hassignals=false)
+    hassignals && error("signal outputs are outside the accelerated path")
+    h1 = ["state_$i" for i in 1:opt.D]
+    h2 = vec(["trans_$(i)_$(j)" for i in 1:opt.D, j in 1:opt.D])
+    h3 = String[]
+    for h in opt.horizons
+        push!(h3, "forecast_$h"); push!(h3, "forecast_error_$h")
+    end
+    odir = "data/output/$(opt.series)/"          # the reference ignores `dir` here (src/Hmc.jl:741)
+    mkpath(odir)
+    basicsave(samples.μ, samples.obsdates, odir * "filtered_means_$(enddate(opt)).csv", h1)
+    basicsave(samples.σ, samples.obsdates, odir * "filtered_variances_$(enddate(opt)).csv", h1)
+    basicsave(samples.πb[:, end, :], samples.obsdates, odir * "filtered_state_probs_$(enddate(opt)).csv", h1)
+    basicsave(reshape(samples.A, opt.Nrun, :), samples.obsdates, odir * "filtered_trans_probs_$(enddate(opt)).csv", h2)
+    basicsave(samples.forecasts, samples.obsdates, odir * "forecasts_$(enddate(opt)).csv", h3)
+end
+
+end # module
