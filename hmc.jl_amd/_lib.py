@@ -51,7 +51,7 @@ _LIB = None
 
 def build(force=False):
     """Compile libhmcgibbs.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("hmcg.hip", "gibbs_device.hpp")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("hmcg.hip", "gibbs_device.hpp", "gibbs_big.hpp")] + \
            [os.path.join(HERE, "..", "include", "hmcg.h")]
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:

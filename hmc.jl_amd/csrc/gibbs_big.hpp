@@ -1,0 +1,667 @@
+// gibbs_big.hpp -- large-K variant (5 <= K <= 8) of the persistent per-window Gibbs kernel, for
+// BASELINE configs[3] (8 states, T = 5000).  Same phases, barriers and RNG spec as the small-K kernel
+// (gibbs_device.hpp); what changes is where things live and how the loops are shaped:
+//   * a K x K matrix is 64 doubles, so per-step data cannot sit in registers: the window's Y, X, the
+//     sweep's uniforms and the per-step state maps live in (dynamic) LDS, and the loops over a
+//     thread's L = ceil(T/256) consecutive steps are runtime loops;
+//   * the transition matrix is read from LDS, one column at a time (stored transposed so a column is
+//     contiguous), and the pdfs are recomputed in the replay instead of being kept;
+//   * the state map g_{t-1} is built inside the filter replay at step t: the running sums
+//     sum_{r' <= r} pif[t-1,r'] A[r',s] that give pif[t,s] are exactly the cumulative weights of the
+//     draw X[t-1] | X[t] = s (src/Hmc.jl:468-481), and the eps() guard pif[t,s] is at hand -- so
+//     the filtered probabilities never have to be stored (pif is neither kept in registers nor
+//     written to HBM; only pif[T-1,:] leaves the replay);
+//   * transition counts go through per-wave LDS histograms (integer atomics: order-independent),
+//     parameter-draw roles (K + K^2 = 72 at K = 8) and output roles take more than one pass over a wave.
+// Reference lines: as in gibbs_device.hpp.
+#pragma once
+#include "gibbs_device.hpp"
+
+namespace hmcg {
+
+template <int K>
+struct ThetaBufBig {
+    double mu[K], sig2[K], isd[K], coef[K], rho[K];
+    double A[K][K];               // row-major, unsorted labels
+    double At[K][K];              // At[s][r] = A[r][s]: column s contiguous
+    double pi_end[K];
+};
+
+template <int K, int NT>
+struct BigShared {
+    static constexpr int NW = NT / 64;
+    static constexpr int KK = K * K;
+    static constexpr int NG = K + KK;
+    unsigned cnt[NW][KK];         // per-wave transition histograms C_ij (field i*K+j)
+    double red_d1[NW][K], red_d2[NW][K];
+    double pivot[K];
+    int x_end;
+    ThetaBufBig<K> th[2];
+    RngBuf<K> rb[2];
+    double gval[NG];              // gamma variates of the running parameter phase
+    double wtot[NW][KK];
+    uint32_t wmap[NW];
+    double ulast;
+    double bred[NW];
+    double med[2];
+};
+
+template <int K, int NT>
+__global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
+{
+    static_assert(K >= 5 && K <= 8, "large-K kernel (4-bit map entries: K <= 8)");
+    constexpr int NW = NT / 64;
+    constexpr int KK = K * K;
+    constexpr int NG = K + KK;
+    static_assert(NW >= 2, "needs shadow waves");
+    using Sh = BigShared<K, NT>;
+    __shared__ Sh sh;
+    extern __shared__ double dyn_lds[];
+    const int cap = NT * L;
+    double* const ylds = dyn_lds;                                   // [cap] observations
+    double* const uxs = dyn_lds + cap;                              // [cap] uniforms of the running sweep
+    uint32_t* const maps = reinterpret_cast<uint32_t*>(dyn_lds + 2 * (size_t)cap);   // [cap] state maps g_t
+    uint8_t* const xs = reinterpret_cast<uint8_t*>(maps + cap);     // [cap + 8] states
+
+    const int w = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T[w];
+    const int t0 = tid * L;
+    int st = 0;
+    if (T < 2 || T > cap) {
+        if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+        return;
+    }
+
+    // ---- observations into LDS (coalesced), xi = mean(Y) (src/Hmc.jl:136) ----
+    bool bad = false;
+    double part = 0.0;
+    for (int t = tid; t < cap; t += NT) {
+        const double v = t < T ? p.Y[(size_t)w * p.ldY + t] : 0.0;
+        bad |= t < T && !isfinite(v);
+        ylds[t] = v;
+        part += v;
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+        if (tid == 0) atomicOr(&p.status[w], HMCG_ST_NONFINITE);
+        return;
+    }
+    const double xi = block_sum<NW>(part, sh.bred, wave, lane) / (double)T;
+    const int NS = 3 * K + KK + 2 * p.H;
+    const int NCK = NS + K;
+
+    if (tid < K) sh.pivot[tid] = xi;
+    if (p.resume) {
+        for (int t = tid; t < cap; t += NT) xs[t] = t < T ? p.xstate[(size_t)w * p.ldY + t] : 0;
+        if (p.sumacc && tid < K) sh.pivot[tid] = p.sumacc[(size_t)w * NCK + NS + tid];
+    } else if (p.x_init) {
+        for (int t = tid; t < cap; t += NT) xs[t] = t < T ? (uint8_t)p.x_init[(size_t)w * p.ldY + t] : 0;
+    } else {
+        // makeParams (src/Hmc.jl:161-195): see the small-K kernel for the nearest-mean rule
+        double lmin = 1.0e308, lmax = -1.0e308;
+        for (int t = tid; t < T; t += NT) { lmin = fmin(lmin, ylds[t]); lmax = fmax(lmax, ylds[t]); }
+        const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
+        const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
+        for (int i0 = 0; i0 < L; i0 += 4) {                       // median by rank counting, 4 own elements per pass
+            double yo[4];
+            int to[4], rank[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { to[i] = tid + (i0 + i) * NT; yo[i] = (i0 + i < L) ? ylds[to[i] < cap ? to[i] : 0] : 0.0; rank[i] = 0; }
+            for (int j = 0; j < T; ++j) {
+                const double yj = ylds[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rank[i] += (yj < yo[i] || (yj == yo[i] && j < to[i])) ? 1 : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i0 + i < L && to[i] < T && rank[i] == (T - 1) / 2) sh.med[0] = yo[i];
+                if (i0 + i < L && to[i] < T && rank[i] == T / 2) sh.med[1] = yo[i];
+            }
+        }
+        __syncthreads();
+        {
+#pragma clang fp contract(off)
+            const double med = (T & 1) ? sh.med[0] : sh.med[0] / 2 + sh.med[1] / 2;
+            const double R = ymax - ymin;
+            const double lo = med - 0.25 * R, hi = med + 0.25 * R;
+            double mu0[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) mu0[k] = lo + (hi - lo) * ((double)k / (double)(K - 1));
+            mu0[K - 1] = hi;
+            for (int t = tid; t < cap; t += NT) {
+                int best = 0;
+                double bd = fabs(ylds[t] - mu0[0]);
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const double d = fabs(ylds[t] - mu0[k]);
+                    if (d < bd) { bd = d; best = k; }
+                }
+                xs[t] = t < T ? (uint8_t)best : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) if (tid == k) sh.pivot[k] = mu0[k];
+        }
+    }
+    if (tid < 8) xs[cap + tid] = 0;
+    __syncthreads();
+    int x_end = xs[T - 1];
+
+    Rng rng{p.seed_lo, p.seed_hi, p.window_ids ? p.window_ids[w] : p.window_base + (uint32_t)w, 0u};
+    const int shadow_wave = wave - 1;
+    constexpr int NSH = NW - 1;
+
+    // ---- shadow jobs -------------------------------------------------------------------------
+    auto job_prep = [&](int sw) {                    // see gibbs_device.hpp job_prep
+        Rng g = rng;
+        g.sweep = (uint32_t)sw;
+        RngBuf<K>& rb = sh.rb[sw & 1];
+        constexpr int NTASK = 4 * NG + 2 * K;
+        for (int base = 0; base < NTASK; base += 64) {
+            const int task = base + lane;
+            const bool live = task < NTASK;
+            const bool t_rho = task < K;
+            const bool t_gx = !t_rho && task < K + 2 * NG;
+            const bool t_z = !t_rho && !t_gx && task < 2 * K + 2 * NG;
+            const bool t_gl = !t_rho && !t_gx && !t_z;
+            const int gt = t_gx ? task - K : task - (2 * K + 2 * NG);
+            const int role = gt >> 1, j = gt & 1;
+            uint32_t site = SITE_RHO, elem = (uint32_t)task, idx = 0;
+            if (t_gx || t_gl) {
+                site = role < K ? SITE_SIG2 : SITE_A;
+                elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
+                idx = 2u * (uint32_t)j + (t_gl ? 1u : 0u);
+            } else if (t_z) {
+                site = SITE_MU; elem = (uint32_t)(task - (K + 2 * NG));
+            }
+            uint32_t r[4];
+            g.block(site, elem, idx, r);
+            const double lg = log_fast(1.0 - u53(r[0], r[1]));
+            double val = lg;
+            if (t_gx || t_z) val = sqrt_fast(-2.0 * lg) * cos2pi_fast(u53(r[2], r[3]));
+            double rs = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) rs += -__shfl(lg, i, 64);
+            if (live) {
+                if (t_rho) rb.rho[task] = -lg * (1.0 / rs);
+                else if (t_gx) rb.x[role][j] = val;
+                else if (t_z) rb.z[task - (K + 2 * NG)] = val;
+                else if (t_gl) rb.lu[role][j] = val;
+            }
+        }
+    };
+    auto job_uniforms = [&](int sw, int b0, int b1) {
+        Rng g = rng;
+        g.sweep = (uint32_t)sw;
+        for (int b = b0 + lane; b < b1; b += 128) {
+            const int bb = b + 64;
+            uint32_t r[4], q[4];
+            g.block(SITE_X, 0, (uint32_t)b, r);
+            g.block(SITE_X, 0, (uint32_t)bb, q);
+            uxs[2 * b] = u53(r[0], r[1]);
+            if (2 * b + 1 < cap) uxs[2 * b + 1] = u53(r[2], r[3]);
+            if (bb < b1) {
+                uxs[2 * bb] = u53(q[0], q[1]);
+                if (2 * bb + 1 < cap) uxs[2 * bb + 1] = u53(q[2], q[3]);
+            }
+        }
+    };
+    // outputs: parameter roles [0, NP) take ceil(NP/64) passes over wave 1; forecast roles sit on the last wave
+    constexpr int OUT_WAVE = 1, FC_WAVE = NW - 1;
+    constexpr int NP = 3 * K + KK;
+    constexpr int NPASS = (NP + 63) / 64;
+    static_assert(NW > 2, "forecast lanes need their own wave here");
+    double sum_par[NPASS], sum_fc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) sum_par[q] = 0.0;
+    const int fc_e = (wave == FC_WAVE && lane >= 64 - 2 * HMCG_MAXH && lane - (64 - 2 * HMCG_MAXH) < 2 * p.H) ? lane - (64 - 2 * HMCG_MAXH) : -1;
+    int fc_h = 0;
+    double fc_yr = 0.0;
+    if (fc_e >= 0) {
+        fc_h = p.horizons[fc_e >> 1];
+        fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (fc_e >> 1)] : __builtin_nan("");
+    }
+    if (p.resume && p.sumacc) {
+        if (wave == OUT_WAVE) {
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) if (lane + 64 * q < NP) sum_par[q] = p.sumacc[(size_t)w * NCK + lane + 64 * q];
+        }
+        if (fc_e >= 0) sum_fc = p.sumacc[(size_t)w * NCK + NP + fc_e];
+    }
+    auto job_outputs = [&](int sw) {
+        if (sw < p.keep_from) return;
+        const ThetaBufBig<K>& th = sh.th[sw & 1];
+        const int d = sw - p.keep_from;
+        const size_t nrun = (size_t)p.nrun;
+        if (wave == OUT_WAVE) {
+            double mu_u[K];
+            int order[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) mu_u[i] = th.mu[i];
+            sort_order<K>(mu_u, order);
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) {
+                const int orole = lane + 64 * q;
+                if (orole < NP) {
+                    double val;
+                    double* dst = nullptr;
+                    if (orole < 3 * K) {
+                        const int pos = orole % K, which = orole / K;
+                        int src = 0;
+#pragma unroll
+                        for (int qq = 0; qq < K; ++qq) src = (qq == pos) ? order[qq] : src;
+                        val = which == 0 ? th.mu[src] : (which == 1 ? th.sig2[src] : th.pi_end[src]);
+                        double* base = which == 0 ? p.mu : (which == 1 ? p.sig2 : p.pi_end);
+                        if (base) dst = base + nrun * ((size_t)pos + (size_t)K * w) + d;
+                    } else {
+                        const int e = orole - 3 * K;                 // column-major e = i + K*j
+                        int si = 0, sj = 0;
+#pragma unroll
+                        for (int qq = 0; qq < K; ++qq) { si = (qq == e % K) ? order[qq] : si; sj = (qq == e / K) ? order[qq] : sj; }
+                        val = th.A[si][sj];
+                        if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + d;
+                    }
+                    if (dst) *dst = val;
+                    sum_par[q] += round5(val);
+                }
+            }
+        }
+        if (fc_e >= 0) {
+            double mu_u[K], pe_u[K], A_u[K][K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                mu_u[i] = th.mu[i]; pe_u[i] = th.pi_end[i];
+#pragma unroll
+                for (int j = 0; j < K; ++j) A_u[i][j] = th.A[i][j];
+            }
+            const double fv = forecast_value<K>(mu_u, A_u, pe_u, fc_h);
+            const double val = (fc_e & 1) ? fv - fc_yr : fv;
+            if (p.fcast) p.fcast[nrun * ((size_t)fc_e + (size_t)(2 * p.H) * w) + d] = val;
+            sum_fc += round5(val);
+        }
+    };
+
+    // ---- sufficient statistics of the chain state in xs[] -------------------------------------
+    auto publish_stats = [&]() {
+        for (int e = lane; e < KK; e += 64) sh.cnt[wave][e] = 0;
+        __builtin_amdgcn_wave_barrier();
+        double d1[K], d2[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { d1[i] = 0.0; d2[i] = 0.0; }
+        for (int l = 0; l < L; ++l) {
+            const int t = t0 + l;
+            if (t < T) {
+                const int xv = xs[t];
+                const double dl = ylds[t] - sh.pivot[xv];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const double dm = (xv == i) ? dl : 0.0;
+                    d1[i] += dm;
+                    d2[i] = fma(dm, dm, d2[i]);
+                }
+                if (t + 1 < T) atomicAdd(&sh.cnt[wave][xv * K + xs[t + 1]], 1u);
+            }
+        }
+        double o0, o1, v8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = i < K ? d1[i] : 0.0;
+        wave_sum8_transposed(v8, lane, o0, o1);
+        if ((lane & 0x3C) == 12) {
+            const int i0 = 4 * (lane & 1) + (lane & 2);
+            if (i0 < K) sh.red_d1[wave][i0] = o0;
+            if (i0 + 1 < K) sh.red_d1[wave][i0 + 1] = o1;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = i < K ? d2[i] : 0.0;
+        wave_sum8_transposed(v8, lane, o0, o1);
+        if ((lane & 0x3C) == 12) {
+            const int i0 = 4 * (lane & 1) + (lane & 2);
+            if (i0 < K) sh.red_d2[wave][i0] = o0;
+            if (i0 + 1 < K) sh.red_d2[wave][i0 + 1] = o1;
+        }
+        if (tid == 0) sh.x_end = x_end;
+    };
+    static_assert(K <= 8, "wave_sum8_transposed carries 8 slots");
+    publish_stats();
+    if (p.sweep_begin < p.sweep_end && shadow_wave == 0) job_prep(p.sweep_begin);
+
+    // pdfs of one observation, scaled by the power of two that brings the largest into [0.5,1)
+    auto pdfs = [&](const ThetaBufBig<K>& th, double yv, bool valid, double (&fv)[K]) {
+        unsigned hm = 0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const double z = (yv - th.mu[s]) * th.isd[s];
+            fv[s] = exp_fast(-0.5 * (z * z)) * th.coef[s];
+            hm = max(hm, (unsigned)__double2hiint(fv[s]));
+        }
+        if (hm < 0x01A56E1Fu) {
+            if (valid) st |= HMCG_ST_EMIS_UNDERFLOW;
+#pragma unroll
+            for (int s = 0; s < K; ++s) fv[s] = 1.0;
+        } else {
+            const int e = 1022 - (int)(hm >> 20);
+#pragma unroll
+            for (int s = 0; s < K; ++s) fv[s] = ldexp(fv[s], e);
+        }
+    };
+
+    for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
+        rng.sweep = (uint32_t)sweep;
+        const int par = sweep & 1;
+        ThetaBufBig<K>& th = sh.th[par];
+        const bool last_sweep = sweep + 1 == p.sweep_end;
+        __syncthreads();                                                     // Ba
+        if (wave == 0) {
+            // ---- parameter draws; roles [0,K) sig2/mu, [K, K+K^2) A entries; ceil(NG/64) passes ----
+            const RngBuf<K>& rb = sh.rb[par];
+            for (int base = 0; base < NG; base += 64) {
+                const int role = base + lane;
+                const bool is_g = role < NG, is_sig = role < K;
+                int c = 0;
+                if (is_g && !is_sig) {
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) c += (int)sh.cnt[ww][role - K];
+                } else if (is_sig) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) c += (int)sh.cnt[ww][role * K + j];
+                    c += (sh.x_end == role) ? 1 : 0;
+                }
+                double shape = 1.0, bpar = 1.0, Neff = 0.0, Ssum = 0.0;
+                if (is_sig) {
+                    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) { d1 += sh.red_d1[ww][role]; d2 += sh.red_d2[ww][role]; }
+                    const double piv = sh.pivot[role];
+                    Neff = (double)c;
+                    const double rn = c > 0 ? rcp_fast(Neff) : 0.0;
+                    const double ybar = c > 0 ? piv + d1 * rn : 0.0;
+                    const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;
+                    Ssum = piv * Neff + d1;
+                    const double beta = (sweep == 0) ? 1.0 : 2.0;
+                    const double dm = ybar - xi;
+                    shape = p.alpha + 0.5 * Neff;
+                    bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);
+                } else if (is_g) {
+                    shape = (double)(c + 1);
+                }
+                double val = 1.0;
+                if (is_g) {
+                    const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
+                    const uint32_t elem = role < K ? (uint32_t)role : (uint32_t)(role - K);
+                    if (shape == 1.0) {
+                        uint32_t r[4];
+                        rng.block(site, elem, 0, r);
+                        val = -log_fast(1.0 - u53(r[0], r[1]));
+                    } else {
+                        const double a = shape < 1.0 ? shape + 1.0 : shape;
+                        const double dd = a - 1.0 / 3.0;
+                        const double cc = rcp_fast(3.0 * sqrt_fast(dd));
+                        val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0]);
+                        if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1]);
+                        if (val < 0.0) {
+                            int j = 2;
+                            for (; j < GAMMA_MAX_ATTEMPTS && val < 0.0; ++j) {
+                                uint32_t r[4];
+                                rng.block(site, elem, 2u * (uint32_t)j, r);
+                                const double xx = box_muller(r);
+                                rng.block(site, elem, 2u * (uint32_t)j + 1u, r);
+                                val = mt_try(dd, cc, xx, log_fast(1.0 - u53(r[0], r[1])));
+                            }
+                            if (val < 0.0) { val = dd; st |= HMCG_ST_GAMMA_CAP; }
+                        }
+                        if (shape < 1.0) {
+                            uint32_t r[4];
+                            rng.block(site, elem, 0xFFFFFFFFu, r);
+                            val *= pow(1.0 - u53(r[0], r[1]), 1.0 / shape);
+                        }
+                    }
+                    sh.gval[role] = val;
+                }
+                if (is_sig) {
+                    const double sig2 = bpar * rcp_fast(val);
+                    const double rnn = rcp_fast(Neff + p.nu);
+                    const double m = (Ssum + p.nu * xi) * rnn;
+                    const double sd = sqrt_fast(sig2);
+                    const double sdev = sd * sqrt_fast(rnn);
+                    const double isd = rcp_fast(sd);
+                    th.mu[role] = m + sdev * rb.z[role];
+                    th.sig2[role] = sig2;
+                    th.isd[role] = isd;
+                    th.coef[role] = INVSQRT2PI * isd;
+                    th.rho[role] = rb.rho[role];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < KK; e += 64) {                // Dirichlet rows of A (:367): normalise in column order
+                const int i = e / K;
+                double gs = 0.0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) gs += sh.gval[K + i * K + j];
+                const double a = sh.gval[K + e] * rcp_fast(gs);
+                th.A[i][e % K] = a;
+                th.At[e % K][i] = a;
+            }
+        } else {
+            const int nblk = (T + 1) >> 1;
+            if (sweep > p.sweep_begin) job_outputs(sweep - 1);
+            if (shadow_wave == NSH - 1 && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
+            const int per = (nblk + NSH - 1) / NSH;
+            job_uniforms(sweep, shadow_wave * per, min((shadow_wave + 1) * per, nblk));
+        }
+        __syncthreads();                                                     // Bb
+        // ---- forward filter: local product of this thread's L matrices A diag(f_t) ----
+        double Q[KK], N[KK];
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
+        auto mstep = [&](const double (&in)[KK], double (&out)[KK], int l) {
+            double fv[K];
+            pdfs(th, ylds[t0 + l], t0 + l < T, fv);
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double a[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) a[k] = th.At[s][k];
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    double acc = in[r * K] * a[0];
+#pragma unroll
+                    for (int k = 1; k < K; ++k) acc = fma(in[r * K + k], a[k], acc);
+                    out[r * K + s] = acc * fv[s];
+                }
+            }
+        };
+        {
+            int l = 0;
+            for (; l + 1 < L; l += 2) {
+                mstep(Q, N, l);
+                mstep(N, Q, l + 1);
+                rescale_pow2<KK>(Q);
+            }
+            if (l < L) {
+                mstep(Q, N, l);
+#pragma unroll
+                for (int i = 0; i < KK; ++i) Q[i] = N[i];
+                rescale_pow2<KK>(Q);
+            }
+        }
+        scan_level<K, DPP_ROW_SHR1, 0xF>(Q);
+        scan_level<K, DPP_ROW_SHR2, 0xF>(Q);
+        rescale_pow2<KK>(Q);
+        scan_level<K, DPP_ROW_SHR4, 0xF>(Q);
+        scan_level<K, DPP_ROW_SHR8, 0xF>(Q);
+        rescale_pow2<KK>(Q);
+        scan_level<K, DPP_ROW_BCAST15, 0xA>(Q);
+        scan_level<K, DPP_ROW_BCAST31, 0xC>(Q);
+        rescale_pow2<KK>(Q);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i) sh.wtot[wave][i] = Q[i];
+        }
+        __syncthreads();                                                     // Bc
+        // prefix vector rho' * (earlier waves) * (exclusive lane prefix)
+        double av[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) av[s] = th.rho[s];
+#pragma unroll
+        for (int ww = 0; ww < NW - 1; ++ww) {
+            double nv[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double acc = av[0] * sh.wtot[ww][s];
+#pragma unroll
+                for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
+                nv[s] = acc;
+            }
+#pragma unroll
+            for (int s = 0; s < K; ++s) av[s] = (ww < wave) ? nv[s] : av[s];
+        }
+        {
+            double nv[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < K; ++r)
+                    acc = fma(av[r], dpp_f64<DPP_WAVE_SHR1, 0xF>((r == s) ? 1.0 : 0.0, Q[r * K + s]), acc);
+                nv[s] = acc;
+            }
+            rescale_pow2<K>(nv);
+#pragma unroll
+            for (int s = 0; s < K; ++s) av[s] = nv[s];
+        }
+        // ---- replay of the normalised recursion (:413-432), fused with the state maps of update_X (:459-484):
+        // at step t the running sums over r of pif[t-1,r] A[r,s] are both pif[t,s]/f and the cumulative
+        // weights of the draw X[t-1] | X[t] = s; the eps() guard is pif[t,s] itself.
+        for (int l = 0; l < L; ++l) {
+            const int t = t0 + l;
+            double fv[K];
+            pdfs(th, ylds[t], t < T, fv);
+            const double u = t >= 1 ? uxs[t - 1] : 0.0;
+            double nv[K], total = 0.0;
+            uint32_t mok = 0;
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double a[K], cum[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) a[k] = th.At[s][k];
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[r] = acc; }
+                const double thr = u * acc;
+                int idx = 0;
+#pragma unroll
+                for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
+                mok |= (uint32_t)idx << (4 * s);
+                nv[s] = acc * fv[s];
+                total += nv[s];
+            }
+            if (!(total > 0.0)) {
+                if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+#pragma unroll
+                for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
+                total = 1.0;
+            }
+            const double inv = rcp_fast(total);
+            int idx_uni = 0;
+            {
+                double cp = 0.0;
+#pragma unroll
+                for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx_uni += (cp <= u) ? 1 : 0; }
+            }
+            uint32_t m = 0;
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                av[s] = nv[s] * inv;                                        // pif[t,s]
+                const uint32_t idx = (av[s] > EPS64) ? ((mok >> (4 * s)) & 15u) : (uint32_t)idx_uni;   // :472-480
+                m |= idx << (4 * s);
+            }
+            if (t >= 1) maps[t - 1] = m;                                     // g_{t-1}; entries at/after T-1 are overridden below
+            if (t == T - 1) {
+#pragma unroll
+                for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
+                sh.ulast = uxs[T - 1];
+            }
+            if (last_sweep && p.pif_final && t < T) {
+#pragma unroll
+                for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t) * K + s] = av[s];
+            }
+        }
+        if (tid == NT - 1) maps[cap - 1] = map_identity<K>();
+        __syncthreads();                                                     // Bd
+        // X[T-1] ~ Categorical(sorted pif[T-1,:]) (:464), redundantly in every thread
+        int xlast = 0;
+        {
+            double mu_u[K];
+            int order[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) mu_u[i] = th.mu[i];
+            sort_order<K>(mu_u, order);
+            const double ulast = sh.ulast;
+            double cp = 0.0;
+#pragma unroll
+            for (int q = 0; q < K - 1; ++q) {
+                cp += th.pi_end[order[q]];
+                xlast += (cp <= ulast) ? 1 : 0;
+            }
+        }
+        // ---- backward sampling: compose this thread's maps, suffix-scan over lanes and waves, apply ----
+        uint32_t G = map_identity<K>();
+        for (int l = L - 1; l >= 0; --l) {
+            const int t = t0 + l;
+            uint32_t m = maps[t];
+            m = (t == T - 1) ? map_const<K>(xlast) : (t > T - 1 ? map_identity<K>() : m);
+            maps[t] = m;
+            G = map_compose<K>(m, G);
+        }
+        uint32_t Hm = G;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t O = __shfl_down(Hm, d, 64);
+            const uint32_t C = map_compose<K>(Hm, O);
+            Hm = (lane + d < 64) ? C : Hm;
+        }
+        if (lane == 0) sh.wmap[wave] = Hm;
+        __syncthreads();                                                     // Be
+        uint32_t Rw = map_identity<K>();
+#pragma unroll
+        for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? map_compose<K>(sh.wmap[ww], Rw) : Rw;
+        uint32_t Hx = __shfl_down(Hm, 1, 64);
+        if (lane == 63) Hx = map_identity<K>();
+        int sin = map_apply(map_compose<K>(Hx, Rw), 0);
+        for (int l = L - 1; l >= 0; --l) {
+            const int t = t0 + l;
+            if (t < T) { sin = map_apply(maps[t], sin); xs[t] = (uint8_t)sin; }
+        }
+        x_end = xlast;
+        if (tid < K) sh.pivot[tid] = th.mu[tid];                             // pivots of the next one-pass statistics
+        __syncthreads();                                                     // Bf: xs, pivot complete
+        publish_stats();
+    }
+
+    // ---- epilogue ----
+    __syncthreads();
+    if (p.sweep_end > p.sweep_begin) job_outputs(p.sweep_end - 1);
+    if (p.xstate) for (int t = tid; t < T; t += NT) p.xstate[(size_t)w * p.ldY + t] = xs[t];
+    if (p.x_final) for (int t = tid; t < T; t += NT) p.x_final[(size_t)w * p.ldY + t] = xs[t];
+    if (wave == OUT_WAVE) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int orole = lane + 64 * q;
+            if (orole < NP) {
+                if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_par[q];
+                if (p.summary && p.final_launch) p.summary[(size_t)w * NS + orole] = p.nrun > 0 ? sum_par[q] / (double)p.nrun : __builtin_nan("");
+            }
+        }
+    }
+    if (fc_e >= 0) {
+        if (p.sumacc) p.sumacc[(size_t)w * NCK + NP + fc_e] = sum_fc;
+        if (p.summary && p.final_launch) p.summary[(size_t)w * NS + NP + fc_e] = p.nrun > 0 ? sum_fc / (double)p.nrun : __builtin_nan("");
+    }
+    if (p.sumacc && tid < K) p.sumacc[(size_t)w * NCK + NS + tid] = sh.pivot[tid];
+    if (st) atomicOr(&p.status[w], st);
+}
+
+}  // namespace hmcg

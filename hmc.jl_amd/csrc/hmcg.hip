@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "gibbs_device.hpp"
+#include "gibbs_big.hpp"
 
 namespace {
 
@@ -81,6 +82,17 @@ const Variant g_variants[] = {
     HMCG_VARIANT(4, 1, 256), HMCG_VARIANT(4, 2, 256), HMCG_VARIANT(4, 4, 256), HMCG_VARIANT(4, 8, 256),
 };
 
+using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
+struct BigVariant {
+    int K, NT;
+    BigKernelFn fn;
+};
+const BigVariant g_big_variants[] = {
+    { 5, 256, hmcg::gibbs_sweeps_kernel_big<5, 256> }, { 6, 256, hmcg::gibbs_sweeps_kernel_big<6, 256> },
+    { 7, 256, hmcg::gibbs_sweeps_kernel_big<7, 256> }, { 8, 256, hmcg::gibbs_sweeps_kernel_big<8, 256> },
+};
+constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
+
 const Variant* pick_variant(int K, int maxT, int nt_req)
 {
     const int nt = nt_req > 0 ? nt_req : 256;
@@ -119,11 +131,27 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
     if (resume && !(ex && ex->xstate)) { set_err("HMCG_FLAG_RESUME needs extras.xstate"); return HMCG_E_BADARG; }
     const int maxT = cfg->max_T > 0 ? cfg->max_T : cfg->ldY;
-    const Variant* v = pick_variant(cfg->K, maxT, cfg->threads_per_window);
-    if (!v) {
+    const Variant* v = nullptr;
+    const BigVariant* bv = nullptr;
+    int bigL = 0;
+    size_t dyn = 0;
+    if (cfg->K >= 5) {
+        for (const BigVariant& b : g_big_variants) if (b.K == cfg->K) bv = &b;
+        if (bv) {
+            bigL = (maxT + bv->NT - 1) / bv->NT;
+            dyn = (size_t)bv->NT * bigL * (8 + 8 + 4 + 1) + 16;
+            if (dyn > BIG_MAX_DYN_LDS || (cfg->threads_per_window != 0 && cfg->threads_per_window != bv->NT)) bv = nullptr;
+        }
+    } else {
+        v = pick_variant(cfg->K, maxT, cfg->threads_per_window);
+        if (v) dyn = 0;
+    }
+    if (!v && !bv) {
         set_err("no kernel for K=%d max_T=%d threads_per_window=%d", cfg->K, maxT, cfg->threads_per_window);
         return HMCG_E_UNSUPPORTED;
     }
+    const int vNT = v ? v->NT : bv->NT, vL = v ? v->L : bigL, vK = cfg->K;
+    (void)vK;
     hmcg::KernelParams p{};
     p.Y = dY; p.T = dT; p.yreal = dyreal;
     p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H; p.nrun = cfg->nrun;
@@ -143,17 +171,18 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     if (p.sweep_end < p.sweep_begin) { set_err("sweep_base beyond burnin+nrun"); return HMCG_E_BADARG; }
 
     if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
-    const size_t dyn = sizeof(double) * (size_t)v->NT * v->L;
+    if (bv) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bv->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     if (timing) HIP_TRY(hipEventRecord(g_ctx.ev0, stream));
 #ifdef HMCG_STAMPS
-    const int nwv = v->NT / 64;
+    const int nwv = vNT / 64;
     const size_t ndbg = (size_t)cfg->W * nwv * HMCG_NSTAMP;
     unsigned long long* ddbg = nullptr;
     HIP_TRY(hipMalloc((void**)&ddbg, ndbg * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(ddbg, 0, ndbg * sizeof(unsigned long long), stream));
     p.dbg = ddbg;
 #endif
-    hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)v->NT), dyn, stream, p);
+    if (v) hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)v->NT), 0, stream, p);
+    else hipLaunchKernelGGL(bv->fn, dim3((unsigned)cfg->W), dim3((unsigned)bv->NT), dyn, stream, p, bigL);
     HIP_TRY(hipGetLastError());
 #ifdef HMCG_STAMPS
     {
@@ -164,7 +193,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
         HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         (void)hipFree(ddbg);
         const int nsw = p.sweep_end - p.sweep_begin;
-        fprintf(stderr, "[stamps] K=%d L=%d NT=%d W=%d sweeps=%d: mean cycles per sweep by wave (s_memtime ticks)\n", v->K, v->L, v->NT, cfg->W, nsw);
+        fprintf(stderr, "[stamps] K=%d L=%d NT=%d W=%d sweeps=%d: mean cycles per sweep by wave (s_memtime ticks)\n", vK, vL, vNT, cfg->W, nsw);
         fprintf(stderr, "%-24s", "phase");
         for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, "   wave%-2d", wv);
         fprintf(stderr, "\n");
@@ -192,10 +221,11 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
         HIP_TRY(hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1));
         timing->kernel_ms = ms;
         timing->launches = 1;
-        timing->threads_per_window = v->NT;
-        timing->steps_per_thread = v->L;
+        timing->threads_per_window = vNT;
+        timing->steps_per_thread = vL;
         hipFuncAttributes fa{};
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(v->fn)) == hipSuccess)
+        const void* fptr = v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn);
+        if (hipFuncGetAttributes(&fa, fptr) == hipSuccess)
             timing->lds_bytes = (int32_t)(fa.sharedSizeBytes + dyn);
     }
     return 0;

@@ -61,6 +61,31 @@ def test_ragged_windows_all_chunkings(hmclib, oracle, K):
                              window_ids=idx)
 
 
+@pytest.mark.parametrize("K", [5, 6, 7, 8])
+def test_large_k_kernel(hmclib, oracle, K):
+    """The large-K variant (LDS-resident window, fused filter-replay/state-map construction)."""
+    lens = [2, 64, 65, 300, 700, 1000]
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
+    check_against_oracle(oracle, Y, Tw, K, 3, 10, (1, 12), fut[:, [0, 11]])
+
+
+def test_cfg4_shape_8_states_T5000(hmclib, oracle):
+    """BASELINE configs[3] shape (8-state, T=5000) on a few windows, fewer draws; full-size properties."""
+    K, T, W = 8, 5000, 3
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    g = check_against_oracle(oracle, Y, Tw, K, 2, 6, (12,), fut[:, 11:12])
+    A = np.transpose(g["A"], (0, 3, 2, 1))
+    assert np.max(np.abs(A.sum(axis=3) - 1)) < 1e-12 and (np.diff(np.transpose(g["mu"], (0, 2, 1)), axis=2) > 0).all()
+    # teacher-forced single sweep from random states at full length
+    rng = np.random.default_rng(3)
+    X0 = rng.integers(0, K, size=(W, T)).astype(np.int32)
+    gt = _lib.estimate_batch_host(Y, Tw, K, 0, 1, (), None, x_init=X0, want_state=True)
+    for w in range(W):
+        o = oracle.estimate_window(Y[w], K, 0, 1, (), None, window_id=w, x_init=X0[w])
+        assert np.array_equal(gt["x_final"][w], o["x_final"])
+        assert np.max(np.abs(gt["pif_final"][w] - o["pif_final"])) < TOL
+
+
 def test_mixed_lengths_in_one_call(hmclib, oracle):
     lens = [1000, 17, 400, 2]
     Y, Tw, fut = synth.generate_panel(4, 1000, 3, ragged=lens)
@@ -121,6 +146,8 @@ def test_status_flags(hmclib, oracle):
         _lib.estimate_batch_host(np.zeros((1, 20000)), [20000], 3, 1, 1)
     with pytest.raises(_lib.HmcgError):
         _lib.estimate_batch_host(np.zeros((1, 100)), [100], 9, 1, 1)
+    with pytest.raises(_lib.HmcgError, match="no kernel"):
+        _lib.estimate_batch_host(np.zeros((1, 9000)), [9000], 8, 1, 1)
 
 
 def test_sharding_reproduces_unsharded_rows(hmclib):
