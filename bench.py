@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--threads-per-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="multi-rank plumbing rehearsal on a one-GPU box: every rank uses cuda:0 and the process group "
+                         "is gloo (RCCL refuses two ranks on one device); never used for reported numbers")
     args = ap.parse_args()
 
     import torch
@@ -98,10 +101,15 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: hmc.jl_amd has no CPU fallback")
+    if args.rehearse_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W_total = W_PER_GPU * world
     ids = list(range(rank * W_PER_GPU, (rank + 1) * W_PER_GPU))
@@ -129,7 +137,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_shared_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     bad = int((panel.status != 0).sum().item())
@@ -152,6 +160,7 @@ def main():
             "value": value, "unit": "Gibbs draws/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "rehearsal": bool(args.rehearse_shared_gpu),
             "config": {"workload": "configs[1]: 3-state Gaussian HMM, T=1000, 256 windows per GPU, 0 burn-in + 1000 "
                                    "draws per window per step, h=12 forecast per draw, on-device summary means",
                        "K": K, "T": T, "windows_per_gpu": W_PER_GPU, "draws_per_window": DRAWS,

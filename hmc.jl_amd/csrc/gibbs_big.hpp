@@ -44,6 +44,9 @@ struct BigShared {
     double ulast;
     double bred[NW];
     double med[2];
+    double fcM[2][K * K];         // forecast scratch (cooperative matrix power on the forecast wave)
+    double fcv[2][K];
+    double fcval[HMCG_MAXH];
 };
 
 template <int K, int NT>
@@ -214,10 +217,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) sum_par[q] = 0.0;
     const int fc_e = (wave == FC_WAVE && lane >= 64 - 2 * HMCG_MAXH && lane - (64 - 2 * HMCG_MAXH) < 2 * p.H) ? lane - (64 - 2 * HMCG_MAXH) : -1;
-    int fc_h = 0;
     double fc_yr = 0.0;
     if (fc_e >= 0) {
-        fc_h = p.horizons[fc_e >> 1];
         fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (fc_e >> 1)] : __builtin_nan("");
     }
     if (p.resume && p.sumacc) {
@@ -265,15 +266,52 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 }
             }
         }
-        if (fc_e >= 0) {
-            double mu_u[K], pe_u[K], A_u[K][K];
+        if (wave == FC_WAVE && p.H > 0) {
+            // (pi' A^h) . mu (src/Hmc.jl:658-667) by binary exponentiation, the whole wave cooperating: lane e
+            // owns entry e of the matrix being squared, lanes < K the vector; operands live in LDS scratch
+            // (the wave's own LDS operations are ordered, so a compiler fence is all that separates the steps)
+            for (int hi = 0; hi < p.H; ++hi) {
+                double* M = sh.fcM[0];
+                double* M2 = sh.fcM[1];
+                double* vv = sh.fcv[0];
+                double* vv2 = sh.fcv[1];
+                if (lane < KK) M[lane] = th.A[lane / K][lane % K];
+                if (lane < K) vv[lane] = th.mu[lane];
+                __builtin_amdgcn_wave_barrier();
+                for (unsigned hh = (unsigned)p.horizons[hi]; hh != 0; hh >>= 1) {
+                    if (hh & 1u) {
+                        if (lane < K) {
+                            double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                mu_u[i] = th.mu[i]; pe_u[i] = th.pi_end[i];
+                            for (int j = 0; j < K; ++j) acc = fma(M[lane * K + j], vv[j], acc);
+                            vv2[lane] = acc;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        double* t = vv; vv = vv2; vv2 = t;
+                    }
+                    if (hh > 1u) {
+                        if (lane < KK) {
+                            const int i = lane / K, j = lane % K;
+                            double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < K; ++j) A_u[i][j] = th.A[i][j];
+                            for (int k = 0; k < K; ++k) acc = fma(M[i * K + k], M[k * K + j], acc);
+                            M2[lane] = acc;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        double* t = M; M = M2; M2 = t;
+                    }
+                }
+                if (lane == 0) {
+                    double fv0 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) fv0 = fma(th.pi_end[i], vv[i], fv0);
+                    sh.fcval[hi] = fv0;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            const double fv = forecast_value<K>(mu_u, A_u, pe_u, fc_h);
+        }
+        if (fc_e >= 0) {
+            const double fv = sh.fcval[fc_e >> 1];
             const double val = (fc_e & 1) ? fv - fc_yr : fv;
             if (p.fcast) p.fcast[nrun * ((size_t)fc_e + (size_t)(2 * p.H) * w) + d] = val;
             sum_fc += round5(val);
@@ -457,6 +495,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
             for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
         auto mstep = [&](const double (&in)[KK], double (&out)[KK], int l) {
+            asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
             double fv[K];
             pdfs(th, ylds[t0 + l], t0 + l < T, fv);
 #pragma unroll
@@ -487,14 +526,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 rescale_pow2<KK>(Q);
             }
         }
-        scan_level<K, DPP_ROW_SHR1, 0xF>(Q);
-        scan_level<K, DPP_ROW_SHR2, 0xF>(Q);
+        scan_level_rowwise<K, DPP_ROW_SHR1, 0xF>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(Q, N);
         rescale_pow2<KK>(Q);
-        scan_level<K, DPP_ROW_SHR4, 0xF>(Q);
-        scan_level<K, DPP_ROW_SHR8, 0xF>(Q);
+        scan_level_rowwise<K, DPP_ROW_SHR4, 0xF>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_SHR8, 0xF>(Q, N);
         rescale_pow2<KK>(Q);
-        scan_level<K, DPP_ROW_BCAST15, 0xA>(Q);
-        scan_level<K, DPP_ROW_BCAST31, 0xC>(Q);
+        scan_level_rowwise<K, DPP_ROW_BCAST15, 0xA>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_BCAST31, 0xC>(Q, N);
         rescale_pow2<KK>(Q);
         if (lane == 63) {
 #pragma unroll
@@ -536,6 +575,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         // at step t the running sums over r of pif[t-1,r] A[r,s] are both pif[t,s]/f and the cumulative
         // weights of the draw X[t-1] | X[t] = s; the eps() guard is pif[t,s] itself.
         for (int l = 0; l < L; ++l) {
+            asm volatile("" ::: "memory");       // as above: A stays in LDS
             const int t = t0 + l;
             double fv[K];
             pdfs(th, ylds[t], t < T, fv);

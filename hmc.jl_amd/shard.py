@@ -53,6 +53,9 @@ def gather_blocks(local_block, local_ids, W_total, group=None, dst=0):
         out[ids] = local_block
         return out
     rank = dist.get_rank(group)
+    if local_block.is_cuda and dist.get_backend(group) == "gloo":
+        local_block = local_block.cpu()          # gloo gathers host tensors (CPU tests, one-GPU rehearsals)
+        ids = ids.cpu()
     cap = -(-W_total // world)
     C = local_block.shape[1]
     pad = torch.zeros((cap, C + 1), dtype=local_block.dtype, device=local_block.device)
