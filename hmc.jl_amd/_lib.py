@@ -33,12 +33,15 @@ class Config(C.Structure):
                 ("max_T", C.c_int32), ("burnin", C.c_int32), ("nrun", C.c_int32), ("H", C.c_int32),
                 ("horizons", C.c_int32 * HMCG_MAXH), ("seed", C.c_uint64), ("window_base", C.c_uint32),
                 ("device", C.c_int32), ("flags", C.c_int32), ("threads_per_window", C.c_int32),
-                ("sweep_base", C.c_int32), ("sweep_count", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double)]
+                ("sweep_base", C.c_int32), ("sweep_count", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double),
+                ("kappa", C.c_double), ("n_samples", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class Extras(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("x_init", C.c_void_p),
-                ("x_final", C.c_void_p), ("pif_final", C.c_void_p), ("xstate", C.c_void_p), ("sumacc", C.c_void_p), ("window_ids", C.c_void_p)]
+                ("x_final", C.c_void_p), ("pif_final", C.c_void_p), ("xstate", C.c_void_p), ("sumacc", C.c_void_p), ("window_ids", C.c_void_p),
+                ("sig_range", C.c_void_p), ("save_range", C.c_void_p), ("sigma_signal", C.c_void_p),
+                ("sigvals", C.c_void_p), ("nsave_ld", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -113,7 +116,7 @@ def _check(rc):
 
 
 def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base=0, device=0, flags=0,
-                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0, sweep_count=0):
+                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0, sweep_count=0, kappa=0.0, n_samples=0):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.W, cfg.K, cfg.ldY, cfg.max_T = int(W), int(K), int(ldY), int(max_T)
@@ -127,6 +130,7 @@ def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base
     cfg.device, cfg.flags = int(device), int(flags)
     cfg.threads_per_window, cfg.sweep_base = int(threads_per_window), int(sweep_base)
     cfg.sweep_count = int(sweep_count)
+    cfg.kappa, cfg.n_samples = float(kappa), int(n_samples)
     cfg.alpha, cfg.nu = float(alpha), float(nu)
     return cfg
 
@@ -137,7 +141,8 @@ def _np_ptr(a):
 
 def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, window_base=0, device=0,
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
-                        resume_state=None, sweep_base=0, window_ids=None, sweep_count=0):
+                        resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
+                        sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,)."""
@@ -149,10 +154,11 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     NS = 3 * K + K * K + 2 * H
     yr = None if yreal is None else np.ascontiguousarray(yreal, dtype=np.float64).reshape(W, H)
     out = {}
+    nd = max(int(n_samples), 1) * nrun          # kept draws per window (sample-major on the signal path)
     if want_draws:
-        out["mu"] = np.zeros((W, K, nrun)); out["sig2"] = np.zeros((W, K, nrun))
-        out["A"] = np.zeros((W, K, K, nrun)); out["pi_end"] = np.zeros((W, K, nrun))
-        out["fcast"] = np.zeros((W, 2 * H, nrun))
+        out["mu"] = np.zeros((W, K, nd)); out["sig2"] = np.zeros((W, K, nd))
+        out["A"] = np.zeros((W, K, K, nd)); out["pi_end"] = np.zeros((W, K, nd))
+        out["fcast"] = np.zeros((W, 2 * H, nd))
     out["summary"] = np.zeros((W, NS))
     out["status"] = np.zeros(W, dtype=np.int32)
     ex = Extras()
@@ -164,6 +170,19 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     if window_ids is not None:
         wid = np.ascontiguousarray(window_ids, dtype=np.uint32).reshape(W)
         ex.window_ids = wid.ctypes.data
+    if sig_range is not None:                      # signal Monte-Carlo path (estimatesignals!)
+        sr = np.ascontiguousarray(sig_range, dtype=np.int32).reshape(W, 2)
+        ex.sig_range = sr.ctypes.data
+        if save_range is not None:
+            svr = np.ascontiguousarray(save_range, dtype=np.int32).reshape(W, 2)
+            ex.save_range = svr.ctypes.data
+            nsave = int(max(1, (svr[:, 1] - svr[:, 0]).max()))
+            out["sigvals"] = np.zeros((W, max(int(n_samples), 1), nsave))
+            ex.sigvals = out["sigvals"].ctypes.data
+            ex.nsave_ld = nsave
+        if sigma_signal is not None:
+            ssg = np.ascontiguousarray(sigma_signal, dtype=np.float64).reshape(W)
+            ex.sigma_signal = ssg.ctypes.data
     if want_state:
         out["x_final"] = np.zeros((W, ldY), dtype=np.int32)
         out["pif_final"] = np.zeros((W, ldY, K))
@@ -181,7 +200,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         ex.xstate = out["xstate"].ctypes.data
         ex.sumacc = out["sumacc"].ctypes.data
     cfg = make_config(W, K, ldY, int(T.max()), burnin, nrun, horizons, seed, window_base, device, flags,
-                      threads_per_window, sweep_base, alpha, nu, sweep_count)
+                      threads_per_window, sweep_base, alpha, nu, sweep_count, kappa, n_samples)
     tm = Timing()
     rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
                                _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),

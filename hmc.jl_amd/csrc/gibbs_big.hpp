@@ -229,10 +229,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         if (fc_e >= 0) sum_fc = p.sumacc[(size_t)w * NCK + NP + fc_e];
     }
     auto job_outputs = [&](int sw) {
-        if (sw < p.keep_from) return;
+        const int d = kept_index(p, sw);
+        if (d < 0) return;
         const ThetaBufBig<K>& th = sh.th[sw & 1];
-        const int d = sw - p.keep_from;
-        const size_t nrun = (size_t)p.nrun;
+        const size_t nrun = (size_t)p.nd;
         if (wave == OUT_WAVE) {
             double mu_u[K];
             int order[K];
@@ -692,13 +692,13 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             const int orole = lane + 64 * q;
             if (orole < NP) {
                 if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_par[q];
-                if (p.summary && p.final_launch) p.summary[(size_t)w * NS + orole] = p.nrun > 0 ? sum_par[q] / (double)p.nrun : __builtin_nan("");
+                if (p.summary && p.final_launch) p.summary[(size_t)w * NS + orole] = p.nd > 0 ? sum_par[q] / (double)p.nd : __builtin_nan("");
             }
         }
     }
     if (fc_e >= 0) {
         if (p.sumacc) p.sumacc[(size_t)w * NCK + NP + fc_e] = sum_fc;
-        if (p.summary && p.final_launch) p.summary[(size_t)w * NS + NP + fc_e] = p.nrun > 0 ? sum_fc / (double)p.nrun : __builtin_nan("");
+        if (p.summary && p.final_launch) p.summary[(size_t)w * NS + NP + fc_e] = p.nd > 0 ? sum_fc / (double)p.nd : __builtin_nan("");
     }
     if (p.sumacc && tid < K) p.sumacc[(size_t)w * NCK + NS + tid] = sh.pivot[tid];
     if (st) atomicOr(&p.status[w], st);

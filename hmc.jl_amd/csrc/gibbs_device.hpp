@@ -34,7 +34,7 @@
 
 namespace hmcg {
 
-enum { SITE_SIG2 = 0, SITE_MU = 1, SITE_RHO = 2, SITE_A = 3, SITE_X = 4 };
+enum { SITE_SIG2 = 0, SITE_MU = 1, SITE_RHO = 2, SITE_A = 3, SITE_X = 4, SITE_NOISE = 5 };
 constexpr int GAMMA_MAX_ATTEMPTS = 64;
 constexpr double INVSQRT2PI = 0.3989422804014327;
 constexpr double TWO_PI = 6.283185307179586476925286766559;
@@ -58,7 +58,25 @@ struct KernelParams {
     const int32_t* x_init; int32_t* x_final; double* pif_final; uint8_t* xstate; double* sumacc;
     const uint32_t* window_ids;
     unsigned long long* dbg;   // diagnostic (HMCG_STAMPS) builds only: per-wave phase cycle sums
+    // sampling schedule: n_samples consecutive blocks of (burnin_s discarded + nrun_s kept) sweeps; kept draw
+    // d of global sweep g is (g / per_sample) * nrun_s + (g % per_sample - burnin_s); nd = n_samples * nrun_s
+    // is the leading dimension of the per-draw outputs.  n_samples == 1 is the estimatemodel case.
+    int32_t per_sample, burnin_s, nrun_s, n_samples, nd;
+    // signal Monte-Carlo path (estimatesignals!, src/Hmc.jl:868-914); all null/zero for estimatemodel
+    double kappa;                   // hp.kappa: relative noise of a signal observation
+    const int32_t* sig_range;       // [W][2] signal positions [begin, end) (end == T)
+    const int32_t* save_range;      // [W][2] positions whose noisy values are reported (signalSave)
+    const double* sigma_signal;     // [W] sd of the noise added to the signal positions of each sample
+    double* sigvals;                // [W][n_samples][nsave_ld]
+    int32_t nsave_ld;
 };
+
+// index of the kept draw produced by global sweep g, or -1 during burn-in
+__device__ __forceinline__ int kept_index(const KernelParams& p, int g)
+{
+    const int smp = g / p.per_sample, i = g - smp * p.per_sample;
+    return i >= p.burnin_s ? smp * p.nrun_s + (i - p.burnin_s) : -1;
+}
 
 // ------------------------------------------------------------------ RNG ----
 // Philox4x32-10, counter = (index, site<<16|element, sweep, window), key = seed.
@@ -476,12 +494,15 @@ struct RngBuf {                   // state-independent parts of one sweep's para
     double rho[K];                // the complete rho ~ Dirichlet(1) draw
 };
 
-template <int K, int L, int NT>
+template <int K, int L, int NT, bool SIG>
 struct SweepShared {
     static constexpr int NW = NT / 64;
     static constexpr int NCNT = K + K * K;
-    static constexpr int NPK = (K * K + 1) / 2;
-    unsigned red_pk[NW][NPK];     // per-wave transition counts C_ij, two 16-bit fields per word (field e = i*K+j)
+    static constexpr int NF = K * K + (SIG ? K : 0);     // count fields: C_ij, then (signal path) M_i = signal steps in state i
+    static constexpr int NPK = (NF + 1) / 2;
+    unsigned red_pk[NW][NPK];     // per-wave counts, two 16-bit fields per word (field e = i*K+j; K*K+i for M_i)
+    double red_s1[SIG ? NW : 1][K];   // signal path: the same pivoted sums over the signal positions
+    double red_s2[SIG ? NW : 1][K];
     int x_end;                    // X[T-1] of the chain state the statistics describe
     double red_d1[NW][K];         // per-wave sums of (y - pivot_i) by state
     double red_d2[NW][K];         // per-wave sums of (y - pivot_i)^2 by state
@@ -564,7 +585,7 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 
 // ------------------------------------------------------------- kernel ----
 
-template <int K, int L, int NT>
+template <int K, int L, int NT, bool SIG = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 {
     static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter-draw roles fit one wave");
@@ -573,7 +594,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     constexpr int KK = K * K;
     constexpr int NG = K + KK;           // gamma roles: sig2_i, then A_ij row-major
     static_assert(NG <= 64, "draw roles must fit wave 0");
-    using Sh = SweepShared<K, L, NT>;
+    using Sh = SweepShared<K, L, NT, SIG>;
     __shared__ Sh sh;
 
     const int w = blockIdx.x;
@@ -603,8 +624,20 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         if (tid == 0) atomicOr(&p.status[w], HMCG_ST_NONFINITE);
         return;
     }
+    // signal path: positions [sb, se) are "signals" (noisy observations); y[] then holds the current
+    // noise sample's Yfake and yreal[] the data
+    int sb = T, se = T;
+    double yreal[SIG ? L : 1];
+    const double kfac = SIG ? 1.0 / (1.0 + p.kappa) : 1.0;
+    if constexpr (SIG) {
+        if (p.sig_range) { sb = p.sig_range[2 * w]; se = p.sig_range[2 * w + 1]; }
+        if (sb >= se) { sb = T; se = T; }
+#pragma unroll
+        for (int l = 0; l < L; ++l) yreal[l] = y[l];
+    }
+    (void)kfac; (void)yreal; (void)sb; (void)se;
 
-    // ---- HyperParams(Y,D): xi = mean(Y)  (src/Hmc.jl:136) ----
+    // ---- HyperParams(Y,D): xi = mean(Y)  (src/Hmc.jl:136); always the mean of the REAL window ----
     double part = 0.0;
 #pragma unroll
     for (int l = 0; l < L; ++l) part += y[l];
@@ -778,7 +811,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0;
     double fc_yr = 0.0;
     {
-        const size_t nrun = (size_t)p.nrun;
+        const size_t nrun = (size_t)p.nd;
         if (orole >= 0 && orole < 3 * K) {
             o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
             double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
@@ -797,9 +830,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     }
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
     auto job_outputs = [&](int sw) {
-        if (sw < p.keep_from || orole < 0) return;
+        const int d = kept_index(p, sw);
+        if (d < 0 || orole < 0) return;
         const ThetaBuf<K>& th = sh.th[sw & 1];
-        const int d = sw - p.keep_from;
         double val;
         if (o_which >= 4) {
             // forecast (src/Hmc.jl:658-667).  (pi' A^h) . mu is invariant under the label permutation, so the
@@ -840,7 +873,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     // per-wave partial statistics of the current X: counts, pivoted sums, transitions
     constexpr int PB = L <= 1 ? 1 : (L <= 3 ? 2 : (L <= 7 ? 3 : (L <= 15 ? 4 : 5)));   // bits holding a per-thread count <= L
     constexpr int FPW = 32 / PB;                       // per-thread fields per 32-bit word
-    constexpr int NWORD = (KK + FPW - 1) / FPW;
+    constexpr int NF = Sh::NF;
+    constexpr int NWORD = (NF + FPW - 1) / FPW;
     constexpr int NPK = Sh::NPK;
     static_assert(64 * L < 65536, "16-bit wave totals");
     auto publish_stats = [&]() {
@@ -862,31 +896,70 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                     acc[wd] += (pv && rel >= 0 && rel < FPW) ? (1u << (PB * rel)) : 0u;
                 }
             }
+            if constexpr (SIG) {                       // M_i: signal steps in state i
+                const int t = t0 + l;
+                const bool sv = t >= sb && t < se;
+                const int c2 = KK + x[l];
+#pragma unroll
+                for (int wd = 0; wd < NWORD; ++wd) {
+                    const int rel = c2 - wd * FPW;
+                    acc[wd] += (sv && rel >= 0 && rel < FPW) ? (1u << (PB * rel)) : 0u;
+                }
+            }
         }
         unsigned pk[NPK];
 #pragma unroll
         for (int d = 0; d < NPK; ++d) {
             const int e0 = 2 * d, e1 = 2 * d + 1;
             unsigned v = (acc[e0 / FPW] >> (PB * (e0 % FPW))) & ((1u << PB) - 1u);
-            if (e1 < KK) v |= ((acc[e1 / FPW] >> (PB * (e1 % FPW))) & ((1u << PB) - 1u)) << 16;
+            if (e1 < NF) v |= ((acc[e1 / FPW] >> (PB * (e1 % FPW))) & ((1u << PB) - 1u)) << 16;
             pk[d] = wave_sum_u32_lane63(v);
         }
-        // ---- pivoted sums by state: d1_i = sum (y - pivot_i), d2_i = sum (y - pivot_i)^2
-        double d1[K], d2[K];
+        // ---- pivoted sums by state: d1_i = sum (y - pivot_i), d2_i = sum (y - pivot_i)^2 over the observation
+        // positions (and, on the signal path, the same two sums over the signal positions)
+        double d1[K], d2[K], s1[SIG ? K : 1], s2[SIG ? K : 1];
 #pragma unroll
         for (int i = 0; i < K; ++i) { d1[i] = 0.0; d2[i] = 0.0; }
+        if constexpr (SIG) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             double pvt = pivot[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) pvt = (x[l] == k) ? pivot[k] : pvt;
             const double dl = y[l] - pvt;
-            const int xs = (t0 + l < T) ? x[l] : -1;
+            const int t = t0 + l;
+            const bool issig = SIG && t >= sb && t < se;
+            const int xs = (t < T && !issig) ? x[l] : -1;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const double dm = (xs == i) ? dl : 0.0;
                 d1[i] += dm;
                 d2[i] = fma(dm, dm, d2[i]);
+            }
+            if constexpr (SIG) {
+                const int xg = issig ? x[l] : -1;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const double dm = (xg == i) ? dl : 0.0;
+                    s1[i] += dm;
+                    s2[i] = fma(dm, dm, s2[i]);
+                }
+            }
+        }
+        if constexpr (SIG) {
+            static_assert(!SIG || K <= 4, "signal path: transposed reduce carries 2 x 4 slots");
+            double v8[8], o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v8[i] = i < K ? s1[i < K ? i : 0] : 0.0; v8[4 + i] = i < K ? s2[i < K ? i : 0] : 0.0; }
+            wave_sum8_transposed(v8, lane, o0, o1);
+            if ((lane & 0x3C) == 12) {
+                const int i0 = lane & 2, i1 = i0 + 1;
+                double* dst = (lane & 1) ? &sh.red_s2[wave][0] : &sh.red_s1[wave][0];
+                if (i0 < K) dst[i0] = o0;
+                if (i1 < K) dst[i1] = o1;
             }
         }
         if constexpr (K <= 4) {
@@ -918,6 +991,32 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             sh.x_end = x_end;
         }
     };
+    // a new noise sample (src/Hmc.jl:892): Yfake = Yreal + N(0,1) * sigma_signal on the signal range; the chain
+    // state carries over (:889-895) and the statistics are retaken on the new data
+    auto regen_y = [&](int smp, bool report) {
+        if constexpr (SIG) {
+            const double ssig = p.sigma_signal ? p.sigma_signal[w] : 0.0;
+            const bool noisy = ssig != 0.0 || p.n_samples > 1;
+            int svb = 0, sve = 0;
+            if (p.save_range) { svb = p.save_range[2 * w]; sve = p.save_range[2 * w + 1]; }
+            Rng gn = rng;
+            gn.sweep = (uint32_t)smp;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = t0 + l;
+                if (noisy && t >= sb && t < se) {
+                    uint32_t r[4];
+                    gn.block(SITE_NOISE, 0, (uint32_t)t, r);
+                    y[l] = yreal[l] + box_muller(r) * ssig;
+                }
+                if (report && p.sigvals && t >= svb && t < sve && t < T)
+                    p.sigvals[((size_t)w * p.n_samples + smp) * p.nsave_ld + (t - svb)] = y[l];
+            }
+        }
+    };
+    if constexpr (SIG) {
+        if (p.sweep_begin % p.per_sample != 0) regen_y(p.sweep_begin / p.per_sample, false);   // resumed inside a sample
+    }
     publish_stats();
 
     // prologue: the first sweep's state-independent RNG parts
@@ -933,6 +1032,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         rng.sweep = (uint32_t)sweep;
         const int par = sweep & 1;
         ThetaBuf<K>& th = sh.th[par];
+        if constexpr (SIG) {
+            const int smp = sweep / p.per_sample;
+            if (sweep == smp * p.per_sample) { regen_y(smp, true); publish_stats(); }
+        }
         __syncthreads();                                                     // Ba: statistics + rb[par] ready
         STAMP(0);
         if (wave == 0) {
@@ -962,15 +1065,39 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) { d1 += sh.red_d1[ww][role]; d2 += sh.red_d2[ww][role]; }
                     const double piv = sh.pivot[role];
-                    Neff = (double)c;
-                    const double rn = c > 0 ? rcp_fast(Neff) : 0.0;
-                    const double ybar = c > 0 ? piv + d1 * rn : 0.0;             // :259-265, :282-288
-                    const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;  // sum (y-ybar)^2 (:291-294)
-                    Ssum = piv * Neff + d1;                                      // sum of y in the state
                     const double beta = (sweep == 0) ? 1.0 : 2.0;                // quirk 2 (:179, :347)
-                    const double dm = ybar - xi;
-                    shape = p.alpha + 0.5 * Neff;                                // :313
-                    bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
+                    if constexpr (!SIG) {
+                        Neff = (double)c;
+                        const double rn = c > 0 ? rcp_fast(Neff) : 0.0;
+                        const double ybar = c > 0 ? piv + d1 * rn : 0.0;             // :259-265, :282-288
+                        const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;  // sum (y-ybar)^2 (:291-294)
+                        Ssum = piv * Neff + d1;                                      // sum of y in the state
+                        const double dm = ybar - xi;
+                        shape = p.alpha + 0.5 * Neff;                                // :313
+                        bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
+                    } else {
+                        // observation set and signal set (src/Hmc.jl:254-314)
+                        int Mi = 0;
+                        {
+                            const int e = KK + role;
+#pragma unroll
+                            for (int ww = 0; ww < NW; ++ww) Mi += (int)((sh.red_pk[ww][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                        }
+                        const int Ni = c - Mi;
+                        double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) { g1 += sh.red_s1[ww][role]; g2 += sh.red_s2[ww][role]; }
+                        const double dNi = (double)Ni, dMi = (double)Mi;
+                        const double S = piv * dNi + d1, Sm = piv * dMi + g1;                       // sums of y
+                        const double S2 = Ni > 0 ? fmax(d2 - d1 * d1 / dNi, 0.0) : 0.0;            // :291-294
+                        const double Sm2 = Mi > 0 ? fmax(g2 - g1 * g1 / dMi, 0.0) : 0.0;           // :296-300
+                        const double totalbar = (Ni + Mi) > 0 ? (S + Sm) / (dNi + dMi) : 0.0;      // :282-288
+                        Neff = dNi + dMi * kfac;                                                    // :302-303
+                        Ssum = S + Sm;                                                              // :331 (Sm unscaled: quirk 4)
+                        const double dm = totalbar - xi;
+                        shape = p.alpha + 0.5 * dNi + 0.5 * dMi;                                    // :313
+                        bpar = beta + 0.5 * S2 + (0.5 * kfac) * Sm2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
+                    }
                 } else {
                     shape = (double)(c + 1);                                     // :362-365
                 }
@@ -1089,8 +1216,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             unsigned hm = 0;
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                const double z = (y[l] - mu[s]) * isd[s];
-                f[l][s] = exp_fast(-0.5 * (z * z)) * coef[s];
+                double z = (y[l] - mu[s]) * isd[s];
+                double cf = coef[s];
+                if constexpr (SIG) {                 // signal positions: sd scaled by (1 + kappa) (:382, quirk 4)
+                    const bool issig = (t0 + l) >= sb && (t0 + l) < se;
+                    z = issig ? z * kfac : z;
+                    cf = issig ? cf * kfac : cf;
+                }
+                f[l][s] = exp_fast(-0.5 * (z * z)) * cf;
                 hm = max(hm, (unsigned)__double2hiint(f[l][s]));
             }
             if (hm < 0x01A56E1Fu) {                  // largest pdf < 1e-300 (high word of 1e-300 is 0x01A56E1F)
@@ -1324,7 +1457,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     if (orole >= 0) {
         if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;
         if (p.summary && p.final_launch)
-            p.summary[(size_t)w * NS + orole] = p.nrun > 0 ? sum_acc / (double)p.nrun : __builtin_nan("");
+            p.summary[(size_t)w * NS + orole] = p.nd > 0 ? sum_acc / (double)p.nd : __builtin_nan("");
     }
     if (p.sumacc) {
 #pragma unroll

@@ -71,15 +71,20 @@ using KernelFn = void (*)(const hmcg::KernelParams);
 struct Variant {
     int K, L, NT;
     KernelFn fn;
+    bool sig;
 };
 
-#define HMCG_VARIANT(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_> }
+#define HMCG_VARIANT(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, false>, false }
+#define HMCG_VARIANT_SIG(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, true>, true }
 const Variant g_variants[] = {
     HMCG_VARIANT(2, 1, 256), HMCG_VARIANT(2, 2, 256), HMCG_VARIANT(2, 4, 256), HMCG_VARIANT(2, 8, 256),
     HMCG_VARIANT(3, 1, 256), HMCG_VARIANT(3, 2, 256), HMCG_VARIANT(3, 4, 256), HMCG_VARIANT(3, 8, 256),
     HMCG_VARIANT(3, 16, 256),
     HMCG_VARIANT(3, 2, 512), HMCG_VARIANT(3, 8, 128),
     HMCG_VARIANT(4, 1, 256), HMCG_VARIANT(4, 2, 256), HMCG_VARIANT(4, 4, 256), HMCG_VARIANT(4, 8, 256),
+    // signal Monte-Carlo path (estimatesignals!): two-population statistics, per-step emission scale
+    HMCG_VARIANT_SIG(2, 1, 256), HMCG_VARIANT_SIG(2, 2, 256), HMCG_VARIANT_SIG(2, 4, 256),
+    HMCG_VARIANT_SIG(3, 1, 256), HMCG_VARIANT_SIG(3, 2, 256), HMCG_VARIANT_SIG(3, 4, 256), HMCG_VARIANT_SIG(3, 8, 256),
 };
 
 using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
@@ -93,12 +98,12 @@ const BigVariant g_big_variants[] = {
 };
 constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
-const Variant* pick_variant(int K, int maxT, int nt_req)
+const Variant* pick_variant(int K, int maxT, int nt_req, bool sig)
 {
     const int nt = nt_req > 0 ? nt_req : 256;
     const Variant* best = nullptr;
     for (const Variant& v : g_variants) {
-        if (v.K != K || v.NT != nt || v.L * v.NT < maxT) continue;
+        if (v.K != K || v.NT != nt || v.L * v.NT < maxT || v.sig != sig) continue;
         if (!best || v.L < best->L) best = &v;
     }
     return best;
@@ -112,7 +117,7 @@ int validate(const hmcg_config* cfg)
         return HMCG_E_BADARG;
     }
     if (cfg->W < 1 || cfg->K < 2 || cfg->K > HMCG_MAXK || cfg->ldY < 2 || cfg->burnin < 0 || cfg->nrun < 0 ||
-        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0 || cfg->sweep_count < 0) {
+        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0 || cfg->sweep_count < 0 || cfg->n_samples < 0 || cfg->kappa < 0.0) {
         set_err("bad hmcg_config (W=%d K=%d ldY=%d max_T=%d burnin=%d nrun=%d H=%d)", cfg->W, cfg->K, cfg->ldY,
                 cfg->max_T, cfg->burnin, cfg->nrun, cfg->H);
         return HMCG_E_BADARG;
@@ -131,6 +136,13 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
     if (resume && !(ex && ex->xstate)) { set_err("HMCG_FLAG_RESUME needs extras.xstate"); return HMCG_E_BADARG; }
     const int maxT = cfg->max_T > 0 ? cfg->max_T : cfg->ldY;
+    const bool use_sig = ex && (ex->sig_range != nullptr);
+    const int n_samples = cfg->n_samples > 1 ? cfg->n_samples : 1;
+    if (!use_sig && (n_samples > 1 || (ex && (ex->sigma_signal || ex->sigvals)))) {
+        set_err("n_samples / sigma_signal / sigvals need extras.sig_range");
+        return HMCG_E_BADARG;
+    }
+    if (use_sig && cfg->K >= 5) { set_err("signal path: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     const Variant* v = nullptr;
     const BigVariant* bv = nullptr;
     int bigL = 0;
@@ -143,7 +155,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
             if (dyn > BIG_MAX_DYN_LDS || (cfg->threads_per_window != 0 && cfg->threads_per_window != bv->NT)) bv = nullptr;
         }
     } else {
-        v = pick_variant(cfg->K, maxT, cfg->threads_per_window);
+        v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig);
         if (v) dyn = 0;
     }
     if (!v && !bv) {
@@ -156,11 +168,17 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     p.Y = dY; p.T = dT; p.yreal = dyreal;
     p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H; p.nrun = cfg->nrun;
     p.sweep_begin = cfg->sweep_base;
-    p.sweep_end = cfg->burnin + cfg->nrun;
+    p.per_sample = cfg->burnin + cfg->nrun;
+    p.burnin_s = cfg->burnin; p.nrun_s = cfg->nrun; p.n_samples = n_samples; p.nd = n_samples * cfg->nrun;
+    if (p.per_sample < 1) p.per_sample = 1;
+    const int total_sweeps = n_samples * (cfg->burnin + cfg->nrun);
+    p.sweep_end = total_sweeps;
     if (cfg->sweep_count > 0 && cfg->sweep_base + cfg->sweep_count < p.sweep_end) p.sweep_end = cfg->sweep_base + cfg->sweep_count;
     p.keep_from = cfg->burnin;
     p.resume = resume ? 1 : 0;
-    p.final_launch = (p.sweep_end == cfg->burnin + cfg->nrun) ? 1 : 0;
+    p.final_launch = (p.sweep_end == total_sweeps) ? 1 : 0;
+    p.kappa = cfg->kappa;
+    if (ex) { p.sig_range = ex->sig_range; p.save_range = ex->save_range; p.sigma_signal = ex->sigma_signal; p.sigvals = ex->sigvals; p.nsave_ld = ex->nsave_ld; }
     for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.window_base = cfg->window_base;
     p.alpha = cfg->alpha > 0.0 ? cfg->alpha : 1.0;
@@ -168,7 +186,8 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     p.mu = dmu; p.sig2 = dsig2; p.A = dA; p.pi_end = dpi_end; p.fcast = dfcast; p.summary = dsummary;
     p.status = dstatus;
     if (ex) { p.x_init = ex->x_init; p.x_final = ex->x_final; p.pif_final = ex->pif_final; p.xstate = ex->xstate; p.sumacc = ex->sumacc; p.window_ids = ex->window_ids; }
-    if (p.sweep_end < p.sweep_begin) { set_err("sweep_base beyond burnin+nrun"); return HMCG_E_BADARG; }
+    if (p.sweep_end < p.sweep_begin) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
+    if (p.sigvals && p.nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
 
     if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
     if (bv) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bv->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
@@ -291,13 +310,17 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     if (!Y || !T) { set_err("Y and T are required"); return HMCG_E_BADARG; }
     rc = ensure_context(cfg->device);
     if (rc) return rc;
-    const size_t W = (size_t)cfg->W, K = (size_t)cfg->K, ld = (size_t)cfg->ldY, H = (size_t)cfg->H, nrun = (size_t)cfg->nrun;
+    const size_t W = (size_t)cfg->W, K = (size_t)cfg->K, ld = (size_t)cfg->ldY, H = (size_t)cfg->H;
+    const size_t nsmp = cfg->n_samples > 1 ? (size_t)cfg->n_samples : 1;
+    const size_t nrun = nsmp * (size_t)cfg->nrun;        // kept draws per window
     const size_t NS = 3 * K + K * K + 2 * H;
     hipStream_t s = g_ctx.stream;
     DevBuf<double> dY, dyr, dmu, dsig, dA, dpe, dfc, dsum, dpif, dacc;
     DevBuf<int32_t> dT, dst, dxi, dxf;
     DevBuf<uint8_t> dxs;
     DevBuf<uint32_t> dwid;
+    DevBuf<int32_t> dsr, dsv;
+    DevBuf<double> dss, dsvals;
 #define ALLOC(buf, n) do { if ((buf).alloc(n) != 0) { set_err("hipMalloc of %zu elements failed", (size_t)(n)); return HMCG_E_NOMEM; } } while (0)
     ALLOC(dY, W * ld); ALLOC(dT, W); ALLOC(dst, W);
     HIP_TRY(hipMemcpyAsync(dY.p, Y, sizeof(double) * W * ld, hipMemcpyHostToDevice, s));
@@ -326,6 +349,14 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
             else HIP_TRY(hipMemsetAsync(dxs.p, 0, W * ld, s));
             dex.xstate = dxs.p;
         }
+        if (extras->sig_range) { ALLOC(dsr, 2 * W); HIP_TRY(hipMemcpyAsync(dsr.p, extras->sig_range, sizeof(int32_t) * 2 * W, hipMemcpyHostToDevice, s)); dex.sig_range = dsr.p; }
+        if (extras->save_range) { ALLOC(dsv, 2 * W); HIP_TRY(hipMemcpyAsync(dsv.p, extras->save_range, sizeof(int32_t) * 2 * W, hipMemcpyHostToDevice, s)); dex.save_range = dsv.p; }
+        if (extras->sigma_signal) { ALLOC(dss, W); HIP_TRY(hipMemcpyAsync(dss.p, extras->sigma_signal, sizeof(double) * W, hipMemcpyHostToDevice, s)); dex.sigma_signal = dss.p; }
+        if (extras->sigvals && extras->nsave_ld > 0) {
+            ALLOC(dsvals, W * nsmp * (size_t)extras->nsave_ld);
+            HIP_TRY(hipMemsetAsync(dsvals.p, 0, sizeof(double) * W * nsmp * (size_t)extras->nsave_ld, s));
+            dex.sigvals = dsvals.p; dex.nsave_ld = extras->nsave_ld;
+        }
         if (extras->window_ids) { ALLOC(dwid, W); HIP_TRY(hipMemcpyAsync(dwid.p, extras->window_ids, sizeof(uint32_t) * W, hipMemcpyHostToDevice, s)); dex.window_ids = dwid.p; }
         if (extras->sumacc) {
             ALLOC(dacc, W * (NS + K));
@@ -347,6 +378,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     D2H(summary, dsum.p, sizeof(double) * W * NS);
     D2H(status, dst.p, sizeof(int32_t) * W);
     if (extras) {
+        D2H(extras->sigvals, dsvals.p, sizeof(double) * W * nsmp * (size_t)(extras->nsave_ld > 0 ? extras->nsave_ld : 0));
         D2H(extras->x_final, dxf.p, sizeof(int32_t) * W * ld);
         D2H(extras->pif_final, dpif.p, sizeof(double) * W * ld * K);
         D2H(extras->xstate, dxs.p, W * ld);

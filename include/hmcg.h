@@ -91,8 +91,14 @@ typedef struct hmcg_config {
     int32_t sweep_base;      /* global index of the first sweep of this call (0 unless resuming) */
     int32_t sweep_count;     /* sweeps to run in this call; 0 = all remaining (burnin+nrun-sweep_base).  A call that
                                 stops short writes extras.xstate/sumacc so a later RESUME call can continue */
-    double alpha;            /* InvGamma prior sample size, 0 -> 1.0 (HyperParams(Y,D), src/Hmc.jl:137) */
-    double nu;               /* Normal prior sample size,   0 -> 1.0 (src/Hmc.jl:140) */
+    double alpha;            /* InvGamma prior sample size, 0 -> 1.0 (HyperParams(Y,D), src/Hmc.jl:137; 2.0 for HyperParams(opt) :154) */
+    double nu;               /* Normal prior sample size,   0 -> 1.0 (src/Hmc.jl:140; 2.0 for HyperParams(opt) :157) */
+    /* signal Monte-Carlo path (estimatesignals!, src/Hmc.jl:868-914); leave zero for estimatemodel */
+    double kappa;            /* hp.kappa: relative noise of a signal observation (opt.noise :158; 1.0 in the base run :132) */
+    int32_t n_samples;       /* opt.noiseSamples: consecutive chains of burnin+nrun sweeps, each on fresh noise, the chain
+                                state carried over (:889-895); 0 or 1 = a single chain.  Outputs then hold n_samples*nrun
+                                draws (sample-major), burnin/nrun being opt.signalburnin/opt.signalNrun */
+    int32_t reserved1;
 } hmcg_config;
 
 /* Optional debug / teacher-forcing / checkpoint buffers (all may be NULL).  Pointer
@@ -110,6 +116,14 @@ typedef struct hmcg_extras {
                                 the one-pass sufficient statistics (so that a resumed chain is bit-identical) */
     const uint32_t* window_ids; /* [W] explicit RNG stream ids (NULL: window_base + w); lets a sharded /
                                    load-balanced run reproduce the unsharded one window for window */
+    /* signal path (all NULL for estimatemodel).  Positions are 0-based and window-relative. */
+    const int32_t* sig_range;   /* [W][2] signal positions [begin, end): opt.signalRange; end must equal T[w]
+                                   (signals reaching past endIndex, sigLen > 0, are not supported) */
+    const int32_t* save_range;  /* [W][2] positions reported in sigvals: opt.signalSave */
+    const double* sigma_signal; /* [W] opt.sigma_signal: sd of the N(0,1) noise added to the signal positions (:892) */
+    double* sigvals;            /* [W][n_samples][nsave_ld] Yfake[signalSave] of every noise sample (:904) */
+    int32_t nsave_ld;
+    int32_t reserved2;
 } hmcg_extras;
 
 typedef struct hmcg_timing {

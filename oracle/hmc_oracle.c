@@ -56,7 +56,7 @@
 #define ST_NONFINITE 4      /* non-finite input */
 #define ST_GAMMA_CAP 8      /* gamma rejection loop hit its attempt cap */
 
-enum { SITE_SIG2 = 0, SITE_MU = 1, SITE_RHO = 2, SITE_A = 3, SITE_X = 4 };
+enum { SITE_SIG2 = 0, SITE_MU = 1, SITE_RHO = 2, SITE_A = 3, SITE_X = 4, SITE_NOISE = 5 };
 
 /* ------------------------------------------------------------------ RNG -- */
 
@@ -200,6 +200,10 @@ typedef struct {
     int *obs_index;      /* [T] stand-in for opt.obsRangeit (faithful-cost mode) */
     int faithful_cost;
     int status;
+    /* signal set (src/Hmc.jl:23,29): 0-based half-open range of window positions that are "signals";
+     * empty for the live estimatemodel caller.  kappa = hp.kappa (relative noise of a signal). */
+    int sig_b, sig_e;
+    double kappa;
 } chain_t;
 
 #define PIF(c, t, s) ((c)->pif[(size_t)(t) * (c)->K + (s)])
@@ -272,26 +276,37 @@ static int in_obs_range(const chain_t *c, int t1)
     return 0;
 }
 
-/* update_mu_sigma (src/Hmc.jl:231-336), signal set empty (live caller). */
+/* update_mu_sigma (src/Hmc.jl:231-336): observation set and signal set (empty for the live caller). */
 static void update_mu_sigma(chain_t *c, const rng_t *g)
 {
     const int K = c->K, T = c->T;
-    long Ni[HMCO_MAXK];
-    double S[HMCO_MAXK], ybar[HMCO_MAXK], totalbar[HMCO_MAXK], S2[HMCO_MAXK];
-    for (int i = 0; i < K; ++i) { Ni[i] = 0; S[i] = 0.0; S2[i] = 0.0; }
-    for (int t = 0; t < T; ++t) { int i = c->X[t]; Ni[i] += 1; S[i] += c->Y[t]; }   /* :254-258 */
-    for (int i = 0; i < K; ++i) ybar[i] = Ni[i] > 0 ? S[i] / (double)Ni[i] : 0.0;    /* :259-265 */
-    for (int i = 0; i < K; ++i) totalbar[i] = Ni[i] > 0 ? (S[i] + 0.0) / (double)(Ni[i] + 0) : 0.0; /* :282-288 */
-    for (int t = 0; t < T; ++t) {                                                     /* :291-294 */
+    const double kap = c->kappa;
+    long Ni[HMCO_MAXK], Mi[HMCO_MAXK];
+    double S[HMCO_MAXK], Sm[HMCO_MAXK], ybar[HMCO_MAXK], sbar[HMCO_MAXK], totalbar[HMCO_MAXK], S2[HMCO_MAXK], Sm2[HMCO_MAXK];
+    for (int i = 0; i < K; ++i) { Ni[i] = 0; Mi[i] = 0; S[i] = 0.0; Sm[i] = 0.0; S2[i] = 0.0; Sm2[i] = 0.0; }
+    for (int t = 0; t < T; ++t) {                                                     /* :254-258, :268-272 */
         int i = c->X[t];
-        double dlt = c->Y[t] - ybar[i];
-        S2[i] += dlt * dlt;
+        if (t >= c->sig_b && t < c->sig_e) { Mi[i] += 1; Sm[i] += c->Y[t]; }
+        else { Ni[i] += 1; S[i] += c->Y[t]; }
     }
     for (int i = 0; i < K; ++i) {
-        double Neff = (double)Ni[i];                                                  /* :302-303, Mi=0 */
-        double a = c->alpha + 0.5 * (double)Ni[i] + 0.5 * 0.0;                        /* :313 */
+        ybar[i] = Ni[i] > 0 ? S[i] / (double)Ni[i] : 0.0;                             /* :259-265 */
+        sbar[i] = Mi[i] > 0 ? Sm[i] / (double)Mi[i] : 0.0;                            /* :273-279 */
+        totalbar[i] = (Ni[i] + Mi[i]) > 0 ? (S[i] + Sm[i]) / (double)(Ni[i] + Mi[i]) : 0.0; /* :282-288 */
+    }
+    for (int t = 0; t < T; ++t) {                                                     /* :291-300 */
+        int i = c->X[t];
+        if (t >= c->sig_b && t < c->sig_e) { double d = c->Y[t] - sbar[i]; Sm2[i] += d * d; }
+        else { double d = c->Y[t] - ybar[i]; S2[i] += d * d; }
+    }
+    double Neff[HMCO_MAXK];
+    for (int i = 0; i < K; ++i) {
+        double Meff = (double)Mi[i] / (1.0 + kap);                                    /* :302 */
+        Neff[i] = (double)Ni[i] + Meff;                                               /* :303 */
+        double a = c->alpha + 0.5 * (double)Ni[i] + 0.5 * (double)Mi[i];              /* :313 */
         double dm = totalbar[i] - c->xi;
-        double b = c->beta[i] + 0.5 * S2[i] + 0.0 + 0.5 * Neff * c->nu / (Neff + c->nu) * (dm * dm); /* :314 */
+        double b = c->beta[i] + 0.5 * S2[i] + (0.5 / (1.0 + kap)) * Sm2[i]
+                 + 0.5 * Neff[i] * c->nu / (Neff[i] + c->nu) * (dm * dm);             /* :314 */
         if (a > 0.0 && b > 0.0) {
             /* InverseGamma(a,b) = 1/Gamma(a, scale 1/b)  (:320) */
             double gdraw = rng_gamma(g, SITE_SIG2, (uint32_t)i, a, &c->status);
@@ -301,10 +316,9 @@ static void update_mu_sigma(chain_t *c, const rng_t *g)
         }
     }
     for (int i = 0; i < K; ++i) {
-        double Neff = (double)Ni[i];
-        double m = (S[i] + 0.0 + c->nu * c->xi) / (Neff + c->nu);                     /* :331 */
-        double s = sqrt(c->sig2[i] / (Neff + c->nu));                                 /* :332 */
-        c->mu[i] = m + s * rng_normal(g, SITE_MU, (uint32_t)i, 0);                    /* :334 */
+        double m = (S[i] + Sm[i] + c->nu * c->xi) / (Neff[i] + c->nu);                /* :331 (Sm not divided by 1+kappa: quirk 4) */
+        double sdev = sqrt(c->sig2[i] / (Neff[i] + c->nu));                           /* :332 */
+        c->mu[i] = m + sdev * rng_normal(g, SITE_MU, (uint32_t)i, 0);                 /* :334 */
     }
 }
 
@@ -346,15 +360,17 @@ static void forward_update(chain_t *c)
 {
     const int K = c->K, T = c->T;
     double sd[HMCO_MAXK], f[HMCO_MAXK];
-    for (int s = 0; s < K; ++s) sd[s] = sqrt(c->sig2[s]);                             /* :381 */
+    double sds[HMCO_MAXK];
+    for (int s = 0; s < K; ++s) { sd[s] = sqrt(c->sig2[s]); sds[s] = (1.0 + c->kappa) * sqrt(c->sig2[s]); }   /* :381-382 (quirk 4) */
     for (int t = 0; t < T; ++t) {
         (void)in_obs_range(c, t + 1);                                                 /* :387, :409 */
+        const double *sdt = (t >= c->sig_b && t < c->sig_e) ? sds : sd;
         double fmax = 0.0;
         if (c->faithful_cost) {
             /* the reference evaluates the pdf inside the r loop: K^2 evaluations (:415) */
-            for (int s = 0; s < K; ++s) for (int r = 0; r < K; ++r) { volatile double v = normpdf(c->mu[s], sd[s], c->Y[t]); f[s] = v; }
+            for (int s = 0; s < K; ++s) for (int r = 0; r < K; ++r) { volatile double v = normpdf(c->mu[s], sdt[s], c->Y[t]); f[s] = v; }
         } else {
-            for (int s = 0; s < K; ++s) f[s] = normpdf(c->mu[s], sd[s], c->Y[t]);
+            for (int s = 0; s < K; ++s) f[s] = normpdf(c->mu[s], sdt[s], c->Y[t]);
         }
         for (int s = 0; s < K; ++s) if (f[s] > fmax) fmax = f[s];
         if (!(fmax >= 1e-300)) {
@@ -495,16 +511,106 @@ double hmco_forecast(int K, const double *mu, const double *A_rowmajor, const do
 
 /* ------------------------------------------------------------ entry ------ */
 
-/* gibbssample + estimatemodel (src/Hmc.jl:517-562, 850-865) for ONE window.
- * Output arrays use the Julia (column-major) layouts of the reference:
- *   mu, sig2, pi_end : (nrun, K)      -> [k*nrun + d]
- *   A                : (nrun, K, K)   -> [(j*K + i)*nrun + d]
- *   fcast            : (nrun, 2H)     -> [(2h+{0,1})*nrun + d]
- *   pi_smooth        : (nrun, T, K)   -> [(k*T + t)*nrun + d]   (optional)
+/* gibbssample + estimatemodel (src/Hmc.jl:517-562, 850-865) for ONE window, generalised to the
+ * signal Monte-Carlo loop of estimatesignals! (src/Hmc.jl:868-914) when n_samples/sigma_signal say so.
+ * Output arrays use the Julia (column-major) layouts of the reference, nd = n_samples*nrun draws:
+ *   mu, sig2, pi_end : (nd, K)      -> [k*nd + d]
+ *   A                : (nd, K, K)   -> [(j*K + i)*nd + d]
+ *   fcast            : (nd, 2H)     -> [(2h+{0,1})*nd + d]
+ *   pi_smooth        : (nd, T, K)   -> [(k*T + t)*nd + d]   (optional)
  *   summary          : 3K + K^2 + 2H means of 5-digit-rounded draws, order
  *                      mu | sig2 | pi_end | A(:) col-major | forecasts  (optional)
+ *   sigvals          : (n_samples, save_e-save_b): Yfake[signalSave] of each noise sample (optional)
+ * Signal model: positions [sig_b, sig_e) (0-based, half-open; must end at T: sigLen = 0, the case the
+ * reference's committed outputs cover) are signals with relative noise kappa.  Each of the n_samples
+ * chains runs burnin+nrun sweeps on Yfake = Y + N(0,1)*sigma_signal over the signal range (:892), and
+ * the chain state is carried from one sample to the next as upstream does (:889-895).  Hyper-
+ * parameters alpha, nu are passed in (1,1 for HyperParams(Y,D) :132-142; 2,2 for HyperParams(opt)
+ * :148-159); xi is always the mean of the REAL window.
  * flags bit0: faithful-cost mode; bit1: run the backward smoother every sweep.
  * Returns 0, or -1 on bad arguments. */
+int hmco_estimate_window_ex(const double *Y, int T, int K, int burnin, int nrun,
+                            const int *horizons, int H, const double *yreal,
+                            uint64_t seed, uint32_t window_id, int flags, const int *x_init,
+                            int sig_b, int sig_e, double kappa, double alpha, double nu,
+                            int n_samples, double sigma_signal, int save_b, int save_e,
+                            double *mu, double *sig2, double *A, double *pi_end, double *fcast,
+                            double *pi_smooth, double *summary, double *sigvals,
+                            int *x_final, double *pif_final, int *status)
+{
+    if (K < 1 || K > HMCO_MAXK || T < 2 || H < 0 || H > HMCO_MAXH || nrun < 0 || burnin < 0 || n_samples < 1) return -1;
+    if (sig_b < sig_e && (sig_b < 0 || sig_e != T)) return -1;       /* only sigLen = 0 */
+    chain_t c;
+    memset(&c, 0, sizeof c);
+    c.K = K; c.T = T;
+    c.faithful_cost = flags & 1;
+    c.sig_b = sig_b < sig_e ? sig_b : T; c.sig_e = sig_b < sig_e ? sig_e : T; c.kappa = kappa;
+    int smoother = (flags & 2) || pi_smooth != NULL;
+    for (int t = 0; t < T; ++t) if (!isfinite(Y[t])) { if (status) *status = ST_NONFINITE; return 0; }
+    double *Yfake = (double *)malloc(sizeof(double) * (size_t)T);
+    memcpy(Yfake, Y, sizeof(double) * (size_t)T);                   /* Yfake = deepcopy(Yreal) (:887) */
+    c.Y = Yfake;
+    c.pif = (double *)malloc(sizeof(double) * (size_t)T * K);
+    c.pib = (double *)malloc(sizeof(double) * (size_t)T * K);
+    c.Pf = (double *)malloc(sizeof(double) * (size_t)T * K * K);
+    c.Pb = (double *)malloc(sizeof(double) * (size_t)T * K * K);
+    c.X = (int *)malloc(sizeof(int) * (size_t)T);
+    c.obs_index = (int *)malloc(sizeof(int) * (size_t)T);
+    chain_init(&c, x_init);                                          /* makeParams on the real data; xi = mean(Yreal) */
+    c.alpha = alpha; c.nu = nu;
+    const int NS = 3 * K + K * K + 2 * H;
+    const int nd = n_samples * nrun;
+    double acc[3 * HMCO_MAXK + HMCO_MAXK * HMCO_MAXK + 2 * HMCO_MAXH];
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+    int order[HMCO_MAXK];
+    rng_t g = { seed, window_id, 0 };
+    for (int smp = 0; smp < n_samples; ++smp) {
+        if (sigma_signal != 0.0 || n_samples > 1) {                  /* :892: fresh noise on the signal range */
+            rng_t gn = { seed, window_id, (uint32_t)smp };
+            for (int t = c.sig_b; t < c.sig_e; ++t)
+                Yfake[t] = Y[t] + rng_normal(&gn, SITE_NOISE, 0, (uint32_t)t) * sigma_signal;
+        }
+        if (sigvals) for (int t = save_b; t < save_e; ++t) sigvals[(size_t)smp * (save_e - save_b) + (t - save_b)] = Yfake[t];
+        for (int it = 0; it < burnin + nrun; ++it) {
+            g.sweep = (uint32_t)(smp * (burnin + nrun) + it);
+            gibbs_sweep(&c, &g, order, smoother);
+            if (it < burnin) continue;
+            const int d = smp * nrun + (it - burnin);
+            double pe[HMCO_MAXK], arow[HMCO_MAXK * HMCO_MAXK];
+            for (int k = 0; k < K; ++k) {
+                pe[k] = PIF(&c, T - 1, order[k]);      /* pib[end,:] == sorted pif[end,:] (:448,:513) */
+                if (mu) mu[(size_t)k * nd + d] = c.mu[k];
+                if (sig2) sig2[(size_t)k * nd + d] = c.sig2[k];
+                if (pi_end) pi_end[(size_t)k * nd + d] = pe[k];
+                acc[k] += round5(c.mu[k]);
+                acc[K + k] += round5(c.sig2[k]);
+                acc[2 * K + k] += round5(pe[k]);
+            }
+            for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+                arow[i * K + j] = c.A[i][j];
+                if (A) A[((size_t)j * K + i) * nd + d] = c.A[i][j];
+                acc[3 * K + j * K + i] += round5(c.A[i][j]);
+            }
+            for (int h = 0; h < H; ++h) {                                             /* :860-862, :905-907 (sigLen = 0) */
+                double f = hmco_forecast(K, c.mu, arow, pe, horizons[h]);
+                double e = f - (yreal ? yreal[h] : NAN);
+                if (fcast) { fcast[(size_t)(2 * h) * nd + d] = f; fcast[(size_t)(2 * h + 1) * nd + d] = e; }
+                acc[3 * K + K * K + 2 * h] += round5(f);
+                acc[3 * K + K * K + 2 * h + 1] += round5(e);
+            }
+            if (pi_smooth)
+                for (int k = 0; k < K; ++k) for (int t = 0; t < T; ++t)
+                    pi_smooth[((size_t)k * T + t) * nd + d] = PIB(&c, t, order[k]);
+        }
+    }
+    if (summary) for (int i = 0; i < NS; ++i) summary[i] = nd > 0 ? acc[i] / nd : NAN;
+    if (x_final) for (int t = 0; t < T; ++t) x_final[t] = c.X[t];
+    if (pif_final) memcpy(pif_final, c.pif, sizeof(double) * (size_t)T * K);
+    if (status) *status = c.status;
+    free(c.pif); free(c.pib); free(c.Pf); free(c.Pb); free(c.X); free(c.obs_index); free(Yfake);
+    return 0;
+}
+
 int hmco_estimate_window(const double *Y, int T, int K, int burnin, int nrun,
                          const int *horizons, int H, const double *yreal,
                          uint64_t seed, uint32_t window_id, int flags, const int *x_init,
@@ -512,62 +618,9 @@ int hmco_estimate_window(const double *Y, int T, int K, int burnin, int nrun,
                          double *pi_smooth, double *summary,
                          int *x_final, double *pif_final, int *status)
 {
-    if (K < 1 || K > HMCO_MAXK || T < 2 || H < 0 || H > HMCO_MAXH || nrun < 0 || burnin < 0) return -1;
-    chain_t c;
-    memset(&c, 0, sizeof c);
-    c.K = K; c.T = T; c.Y = Y;
-    c.faithful_cost = flags & 1;
-    int smoother = (flags & 2) || pi_smooth != NULL;
-    for (int t = 0; t < T; ++t) if (!isfinite(Y[t])) { if (status) *status = ST_NONFINITE; return 0; }
-    c.pif = (double *)malloc(sizeof(double) * (size_t)T * K);
-    c.pib = (double *)malloc(sizeof(double) * (size_t)T * K);
-    c.Pf = (double *)malloc(sizeof(double) * (size_t)T * K * K);
-    c.Pb = (double *)malloc(sizeof(double) * (size_t)T * K * K);
-    c.X = (int *)malloc(sizeof(int) * (size_t)T);
-    c.obs_index = (int *)malloc(sizeof(int) * (size_t)T);
-    chain_init(&c, x_init);
-    const int NS = 3 * K + K * K + 2 * H;
-    double acc[3 * HMCO_MAXK + HMCO_MAXK * HMCO_MAXK + 2 * HMCO_MAXH];
-    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
-    int order[HMCO_MAXK];
-    rng_t g = { seed, window_id, 0 };
-    for (int it = 0; it < burnin + nrun; ++it) {
-        g.sweep = (uint32_t)it;
-        gibbs_sweep(&c, &g, order, smoother);
-        if (it < burnin) continue;
-        const int d = it - burnin;
-        double pe[HMCO_MAXK], arow[HMCO_MAXK * HMCO_MAXK];
-        for (int k = 0; k < K; ++k) {
-            pe[k] = PIF(&c, T - 1, order[k]);      /* pib[end,:] == sorted pif[end,:] (:448,:513) */
-            if (mu) mu[(size_t)k * nrun + d] = c.mu[k];
-            if (sig2) sig2[(size_t)k * nrun + d] = c.sig2[k];
-            if (pi_end) pi_end[(size_t)k * nrun + d] = pe[k];
-            acc[k] += round5(c.mu[k]);
-            acc[K + k] += round5(c.sig2[k]);
-            acc[2 * K + k] += round5(pe[k]);
-        }
-        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
-            arow[i * K + j] = c.A[i][j];
-            if (A) A[((size_t)j * K + i) * nrun + d] = c.A[i][j];
-            acc[3 * K + j * K + i] += round5(c.A[i][j]);
-        }
-        for (int h = 0; h < H; ++h) {                                                 /* :860-862 */
-            double f = hmco_forecast(K, c.mu, arow, pe, horizons[h]);
-            double e = f - (yreal ? yreal[h] : NAN);
-            if (fcast) { fcast[(size_t)(2 * h) * nrun + d] = f; fcast[(size_t)(2 * h + 1) * nrun + d] = e; }
-            acc[3 * K + K * K + 2 * h] += round5(f);
-            acc[3 * K + K * K + 2 * h + 1] += round5(e);
-        }
-        if (pi_smooth)
-            for (int k = 0; k < K; ++k) for (int t = 0; t < T; ++t)
-                pi_smooth[((size_t)k * T + t) * nrun + d] = PIB(&c, t, order[k]);
-    }
-    if (summary) for (int i = 0; i < NS; ++i) summary[i] = nrun > 0 ? acc[i] / nrun : NAN;
-    if (x_final) for (int t = 0; t < T; ++t) x_final[t] = c.X[t];
-    if (pif_final) memcpy(pif_final, c.pif, sizeof(double) * (size_t)T * K);
-    if (status) *status = c.status;
-    free(c.pif); free(c.pib); free(c.Pf); free(c.Pb); free(c.X); free(c.obs_index);
-    return 0;
+    return hmco_estimate_window_ex(Y, T, K, burnin, nrun, horizons, H, yreal, seed, window_id, flags, x_init,
+                                   T, T, 1.0, 1.0, 1.0, 1, 0.0, 0, 0,
+                                   mu, sig2, A, pi_end, fcast, pi_smooth, summary, NULL, x_final, pif_final, status);
 }
 
 /* Batched form over W windows (window-major Y panel, ld = ldY), one window per

@@ -36,6 +36,7 @@ def lib():
             build()
         L = C.CDLL(so)
         L.hmco_estimate_window.restype = C.c_int
+        L.hmco_estimate_window_ex.restype = C.c_int
         L.hmco_estimate_batch.restype = C.c_int
         L.hmco_forward_filter.restype = C.c_int
         L.hmco_backward_smoother.restype = None
@@ -84,6 +85,38 @@ def estimate_window(Y, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, w
     if want_smooth:
         out["pi_smooth"] = sm.transpose(2, 1, 0).copy()  # (nrun, T, K)
     return out
+
+
+def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alpha=1.0, nu=1.0, sigma_signal=0.0,
+                     save=(0, 0), horizons=(12,), yreal=None, seed=1234, window_id=0, x_init=None):
+    """estimatesignals!'s sampling loop (src/Hmc.jl:868-914) for one window; with n_samples=1 and
+    sigma_signal=0 it is the base estimatemodel run on a window that has a signal set.
+    sig/save are 0-based half-open position ranges.  Returns draws as (n_samples*nrun, ...) arrays
+    plus sigvals (n_samples, nsave)."""
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    T = Y.shape[0]
+    H = len(horizons)
+    hz = np.asarray(horizons, dtype=np.int32)
+    yr = np.full(H, np.nan) if yreal is None else np.ascontiguousarray(yreal, dtype=np.float64)
+    nd = n_samples * nrun
+    mu = np.empty((K, nd)); sig2 = np.empty((K, nd)); A = np.empty((K, K, nd))
+    pe = np.empty((K, nd)); fc = np.empty((2 * H, nd))
+    summ = np.empty(3 * K + K * K + 2 * H)
+    nsave = max(save[1] - save[0], 0)
+    sv = np.zeros((n_samples, max(nsave, 1)))
+    xf = np.empty(T, dtype=np.int32); pf = np.empty((T, K))
+    xi = None if x_init is None else np.ascontiguousarray(x_init, dtype=np.int32)
+    st = C.c_int(0)
+    rc = lib().hmco_estimate_window_ex(_p(Y), C.c_int(T), C.c_int(K), C.c_int(burnin), C.c_int(nrun),
+                                       _p(hz, _ip), C.c_int(H), _p(yr), C.c_uint64(seed), C.c_uint32(window_id),
+                                       C.c_int(0), _p(xi, _ip), C.c_int(sig[0]), C.c_int(sig[1]), C.c_double(kappa),
+                                       C.c_double(alpha), C.c_double(nu), C.c_int(n_samples), C.c_double(sigma_signal),
+                                       C.c_int(save[0]), C.c_int(save[1]), _p(mu), _p(sig2), _p(A), _p(pe), _p(fc),
+                                       None, _p(summ), _p(sv), _p(xf, _ip), _p(pf), C.byref(st))
+    if rc != 0:
+        raise ValueError("hmco_estimate_window_ex rc=%d" % rc)
+    return dict(mu=mu.T.copy(), sig2=sig2.T.copy(), A=A.transpose(2, 1, 0).copy(), pi_end=pe.T.copy(),
+                fcast=fc.T.copy(), summary=summ, sigvals=sv[:, :nsave], x_final=xf, pif_final=pf, status=st.value)
 
 
 def estimate_batch(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, window_base=0,

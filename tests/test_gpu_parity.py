@@ -86,6 +86,48 @@ def test_cfg4_shape_8_states_T5000(hmclib, oracle):
         assert np.max(np.abs(gt["pif_final"][w] - o["pif_final"])) < TOL
 
 
+def check_signals_against_oracle(oracle, Y, Tw, K, burnin, nrun, n_samples, sig, save, kappa, alpha, nu, ssig, yreal):
+    W = Y.shape[0]
+    g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), yreal, want_state=True, sig_range=sig, save_range=save,
+                                 sigma_signal=ssig, kappa=kappa, n_samples=n_samples, alpha=alpha, nu=nu)
+    for w in range(W):
+        o = oracle.estimate_signals(Y[w, :Tw[w]], K, burnin, nrun, n_samples, sig=tuple(sig[w]), kappa=kappa, alpha=alpha,
+                                    nu=nu, sigma_signal=float(ssig[w]), save=tuple(save[w]), yreal=yreal[w], window_id=w)
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"]), "state path differs in window %d" % w
+        assert close(g["mu"][w].T, o["mu"]) < TOL and close(g["sig2"][w].T, o["sig2"]) < TOL
+        assert close(np.transpose(g["A"][w], (2, 1, 0)), o["A"]) < TOL and close(g["pi_end"][w].T, o["pi_end"]) < TOL
+        assert close(g["fcast"][w].T, o["fcast"]) < TOL and close(g["summary"][w], o["summary"]) < TOL
+        ns = save[w][1] - save[w][0]
+        assert close(g["sigvals"][w][:, :ns], o["sigvals"]) < TOL
+        assert close(g["pif_final"][w, :Tw[w]], o["pif_final"]) < TOL
+    return g
+
+
+def test_signal_path_all_signal_real_data(hmclib, oracle, inflation):
+    """estimatesignals! in the reference's committed "allsignal" configuration (code/run_hmm.jl:158-175): every
+    position is a signal, HyperParams(opt) (alpha = nu = 2, kappa = noise), noise samples chained."""
+    y, _ = inflation
+    ends = [121, 122, 300]
+    ld = max(ends)
+    Y = np.zeros((3, ld)); Tw = np.array(ends, dtype=np.int32)
+    for i, e in enumerate(ends):
+        Y[i, :e] = y[:e]
+    yreal = np.array([[y[e + 11]] for e in ends])
+    sig = np.array([[0, e] for e in ends]); save = np.array([[e - 2, e] for e in ends])
+    check_signals_against_oracle(oracle, Y, Tw, 3, 6, 15, 4, sig, save, 0.3, 2.0, 2.0, np.array([2.6, 2.5, 1.9]), yreal)
+    # the base run inside estimatesignals! (:869-872): one chain, no noise, HyperParams(Y,D) with kappa = 1
+    check_signals_against_oracle(oracle, Y, Tw, 3, 10, 30, 1, sig, save, 1.0, 1.0, 1.0, np.zeros(3), yreal)
+
+
+def test_signal_path_partial_signal_synthetic(hmclib, oracle):
+    """Signals on the tail of the window only (two populations in the conjugate update), K = 2 and 3, L = 1..4."""
+    for K, T in ((3, 1000), (2, 300), (3, 500)):
+        Y, Tw, fut = synth.generate_panel(3, T, K)
+        sig = np.array([[T - 40, T], [T - 1, T], [T // 2, T]]); save = np.array([[T - 3, T], [T - 1, T], [T - 2, T]])
+        check_signals_against_oracle(oracle, Y, Tw, K, 3, 8, 3, sig, save, 0.6, 2.0, 2.0, np.array([0.5, 1.0, 0.2]), fut[:, 11:12])
+
+
 def test_mixed_lengths_in_one_call(hmclib, oracle):
     lens = [1000, 17, 400, 2]
     Y, Tw, fut = synth.generate_panel(4, 1000, 3, ragged=lens)
