@@ -8,6 +8,7 @@ ABI.  Names, argument meaning and result layout follow the reference:
     makey/startdate/enddate/yobs/yend   src/Hmc.jl:85-107
     makedate            src/Hmc.jl:573-582
     estimatemodel       src/Hmc.jl:850-865   -> (mu, sigma, pib, A, forecasts, obsdates)
+    estimatesignals     src/Hmc.jl:868-914   (estimatesignals!; signal ranges ending at endIndex)
     forecast            src/Hmc.jl:658-667
     saveresults/basicsave   src/Hmc.jl:707-748   (five per-window CSVs)
     runaggregate layout src/Hmc.jl:1025-1078 (`*_summary.csv`)
@@ -27,9 +28,10 @@ class Samples:
     """The NamedTuple estimatemodel returns upstream (src/Hmc.jl:864): fields μ, σ, πb, A,
     forecasts, obsdates (ASCII aliases mu, sigma, pib), plus the window's status word."""
 
-    def __init__(self, μ, σ, πb, A, forecasts, obsdates, status=0):
+    def __init__(self, μ, σ, πb, A, forecasts, obsdates, status=0, signalvals=None, signalids=None):
         self.μ, self.σ, self.πb, self.A = μ, σ, πb, A
         self.forecasts, self.obsdates, self.status = forecasts, obsdates, status
+        self.signalvals, self.signalids = signalvals, signalids      # estimatesignals! only (src/Hmc.jl:913)
 
     mu = property(lambda s: s.μ)
     sigma = property(lambda s: s.σ)
@@ -120,11 +122,25 @@ def _yreal_row(rawdata, endIndex, horizons):
 
 
 def _check_live_path(opt):
-    if len(opt.signalRange) != 0:
-        raise NotImplementedError("signal ranges (estimatesignals!) are outside the accelerated path (SURVEY.md 8f)")
     if opt.sampleRange[0] != 1 or opt.sampleRange != list(range(1, opt.sampleRange[-1] + 1)):
         raise ValueError("sampleRange must be 1:N (the reference indexes window-relative arrays with absolute "
                          "indices, src/Hmc.jl:254,406 -- only windows starting at 1 are meaningful)")
+    sr = opt.signalRange
+    if len(sr):
+        if sr != list(range(sr[0], sr[-1] + 1)) or sr[-1] != opt.sampleRange[-1]:
+            raise NotImplementedError("signalRange must be a contiguous tail of sampleRange")
+        if sr[-1] != opt.endIndex:
+            raise NotImplementedError("signals reaching past endIndex (sigLen > 0, src/Hmc.jl:888,906-910) are not "
+                                      "accelerated: the reference's committed outputs only cover sigLen = 0")
+
+
+def _sig_ranges(opt):
+    """0-based half-open (signal, save) position ranges of the window, or (None, None)."""
+    if not len(opt.signalRange):
+        return None, None
+    sig = (opt.signalRange[0] - 1, opt.signalRange[-1])
+    sv = (opt.signalSave[0] - 1, opt.signalSave[-1]) if len(opt.signalSave) else (0, 0)
+    return sig, sv
 
 
 def _unpack(res, w, nrun, K, H, obsdate):
@@ -142,13 +158,49 @@ def estimatemodel(opt, device=0):
     Returns Samples(μ[Nrun,D], σ[Nrun,D] (variances), πb[Nrun,1,D], A[Nrun,D,D],
     forecasts[Nrun,2H], obsdates).  πb keeps only the window's last time step -- the
     only slice the reference's outputs consume (`samples.πb[:,end,:]`, src/Hmc.jl:744,861)
-    -- so `samples.πb[:, -1, :]` reads exactly as upstream."""
+    -- so `samples.πb[:, -1, :]` reads exactly as upstream.
+
+    If opt carries a signal range the call is the base run of estimatesignals! (:869-872): upstream
+    builds HyperParams(Y, D) there, i.e. alpha = nu = 1 and kappa = 1.0 whatever opt.noise says."""
     _check_live_path(opt)
     Y = makey(opt)
+    sig, sv = _sig_ranges(opt)
+    kw = {}
+    if sig is not None:
+        kw = dict(sig_range=[sig], save_range=[sv], sigma_signal=[0.0], kappa=1.0, n_samples=1)
     res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.burnin, opt.Nrun, tuple(opt.horizons),
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
-                                   device=device)
+                                   device=device, **kw)
     return _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
+
+
+def estimatesignals(opt, device=0):
+    """Hmc.estimatesignals!(opt) (src/Hmc.jl:868-914) on the GPU (the `!`: opt.σsignal is set when it was 0).
+
+    opt.noiseSamples chains of signalburnin + signalNrun sweeps run back to back on
+    Yfake = Yreal + N(0,1) * σsignal over opt.signalRange, the chain state carried from one noise sample
+    to the next as upstream (:889-895), with HyperParams(opt): alpha = nu = 2, kappa = opt.noise (:148-159).
+    Returns Samples with (noiseSamples*signalNrun) draws, sample-major, plus signalvals[Ndraws, len(signalSave)]
+    and signalids[Ndraws] (1-based), as the reference's NamedTuple (:913).  The noise comes from this
+    library's counter-based RNG (site 5), not Julia's stream."""
+    _check_live_path(opt)
+    if not len(opt.signalRange):
+        raise ValueError("estimatesignals needs a signalRange")
+    if opt.σsignal == 0:                                   # isapprox(opt.σsignal, 0) (:869)
+        base = estimatemodel(opt, device=device)
+        opt.σsignal = float(np.mean(base.σ)) * opt.noise  # :871
+    Y = makey(opt)
+    sig, sv = _sig_ranges(opt)
+    n, ns = opt.signalNrun, opt.noiseSamples
+    res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.signalburnin, n, tuple(opt.horizons),
+                                   _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
+                                   device=device, sig_range=[sig], save_range=[sv], sigma_signal=[opt.σsignal],
+                                   kappa=opt.noise, n_samples=ns, alpha=2.0, nu=2.0)
+    s = _unpack(res, 0, ns * n, opt.D, len(opt.horizons), enddate(opt))
+    nsave = len(opt.signalSave)
+    s.signalvals = np.repeat(res["sigvals"][0][:, :nsave], n, axis=0)           # :904
+    s.signalids = np.repeat(np.arange(1, ns + 1), n)                            # :903
+    return s
 
 
 class BatchResult:
@@ -179,6 +231,10 @@ def estimatewindows(rawdata, dates, endIndices, startIndex=1, keep_draws=False, 
     rawdata = np.asarray(rawdata, dtype=np.float64)
     opts = [estopt(rawdata, dates, sampleRange=range(1, int(e) + 1), endIndex=int(e), **kwargs) for e in endIndices]
     o0 = opts[0]
+    for o in opts:
+        _check_live_path(o)
+        if len(o.signalRange):
+            raise NotImplementedError("estimatewindows batches estimatemodel; use estimatesignals per window for signal runs")
     W = len(opts)
     Tw = np.array([len(o.sampleRange) for o in opts], dtype=np.int32)
     ld = int(Tw.max())
@@ -229,33 +285,46 @@ def _header(opt, nfc):
     return h1, h2, h3[:nfc]
 
 
-def basicsave(data, dates, fname, dataheader, precision=5):
-    """src/Hmc.jl:707-722 without signals: round to `precision` digits, date first."""
+def basicsave(data, dates, fname, dataheader, precision=5, signal=None, signalids=None):
+    """src/Hmc.jl:707-722: round to `precision` digits, date first; with signals a `signalid` column follows
+    the date and `signal_i` columns (rounded to 5 digits) close the row."""
     data = np.asarray(data, dtype=np.float64)
     sc = 10.0 ** precision
     rounded = np.rint(data * sc) / sc
+    header = ["date"] + list(dataheader)
+    sig = None
+    if signal is not None and np.asarray(signal).shape[1] > 0:
+        sig = np.rint(np.asarray(signal, dtype=np.float64) * 1e5) / 1e5
+        header += ["signal_%d" % (i + 1) for i in range(sig.shape[1])]
+    if signalids is not None and len(signalids) > 0:
+        header.insert(1, "signalid")
     with open(fname, "w") as f:
-        f.write(",".join(["date"] + list(dataheader)) + "\n")
-        for d, row in zip(dates, rounded):
-            f.write(",".join([str(d)] + [_fmt(v) for v in row]) + "\n")
+        f.write(",".join(header) + "\n")
+        for i, (d, row) in enumerate(zip(dates, rounded)):
+            cells = [str(d)]
+            if sig is not None:                  # the reference only emits signalids together with signals (:715-717)
+                cells.append(str(int(signalids[i])))
+            cells += [_fmt(v) for v in row]
+            if sig is not None:
+                cells += [_fmt(v) for v in sig[i]]
+            f.write(",".join(cells) + "\n")
 
 
 def saveresults(samples, opt, dir, hassignals=False):
     """Five per-window CSVs with the reference's names and columns (src/Hmc.jl:724-748).
-    The reference ignores `dir` when hassignals=false and writes to
-    data/output/<series>/ -- which is what its only caller passes (code/run_hmm.jl:116,120)."""
-    if hassignals:
-        raise NotImplementedError("signal outputs are outside the accelerated path (SURVEY.md 8f)")
+    Without signals the reference ignores `dir` and writes to data/output/<series>/ -- which is what its
+    only caller passes (code/run_hmm.jl:116,120); with signals it writes under `dir` (:735-739)."""
     os.makedirs(dir, exist_ok=True)
     h1, h2, h3 = _header(opt, samples.forecasts.shape[1])
     ed = enddate(opt)
     n = samples.μ.shape[0]
-    basicsave(samples.μ, samples.obsdates, os.path.join(dir, "filtered_means_%s.csv" % ed), h1)
-    basicsave(samples.σ, samples.obsdates, os.path.join(dir, "filtered_variances_%s.csv" % ed), h1)
-    basicsave(samples.πb[:, -1, :], samples.obsdates, os.path.join(dir, "filtered_state_probs_%s.csv" % ed), h1)
+    kw = dict(signal=samples.signalvals, signalids=samples.signalids) if hassignals else {}
+    basicsave(samples.μ, samples.obsdates, os.path.join(dir, "filtered_means_%s.csv" % ed), h1, **kw)
+    basicsave(samples.σ, samples.obsdates, os.path.join(dir, "filtered_variances_%s.csv" % ed), h1, **kw)
+    basicsave(samples.πb[:, -1, :], samples.obsdates, os.path.join(dir, "filtered_state_probs_%s.csv" % ed), h1, **kw)
     basicsave(samples.A.reshape(n, -1, order="F"), samples.obsdates,
-              os.path.join(dir, "filtered_trans_probs_%s.csv" % ed), h2)
-    basicsave(samples.forecasts, samples.obsdates, os.path.join(dir, "forecasts_%s.csv" % ed), h3)
+              os.path.join(dir, "filtered_trans_probs_%s.csv" % ed), h2, **kw)
+    basicsave(samples.forecasts, samples.obsdates, os.path.join(dir, "forecasts_%s.csv" % ed), h3, **kw)
 
 
 SUMMARY_FILES = ("filtered_means", "filtered_variances", "filtered_state_probs", "filtered_trans_probs", "forecasts")

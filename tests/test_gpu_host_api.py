@@ -51,3 +51,50 @@ def test_run_hmm_style_flow_and_summary_files(hmclib, inflation, tmp_path, golde
     s = one.samples(0)
     hmc.saveresults(s, one.opts[0], str(tmp_path / "official"))
     assert len(os.listdir(tmp_path / "official")) == 5
+
+
+def test_estimatesignals_like_run_hmm_allsignal(hmclib, oracle, inflation, tmp_path):
+    """code/run_hmm.jl:158-175: everything a signal, then Hmc.estimatesignals!(opt) and saveresults(hassignals=true)."""
+    y, dates = inflation
+    dd = [dt.date.fromisoformat(d) for d in dates]
+    e = 121
+    opt = hmc.estopt(y, dd, sampleRange=range(1, e + 1), signalRange=range(1, e + 1), signalSave=range(e - 1, e + 1),
+                     endIndex=e, horizons=[12], D=3, burnin=200, Nrun=400, signalburnin=20, signalNrun=30,
+                     noiseSamples=5, noise=0.3, series="official")
+    samples = hmc.estimatesignals(opt)
+    assert opt.σsignal > 0                                             # set by the base run (src/Hmc.jl:869-872)
+    assert samples.μ.shape == (150, 3) and samples.A.shape == (150, 3, 3) and samples.forecasts.shape == (150, 2)
+    assert samples.signalvals.shape == (150, 2) and list(samples.signalids[:31]) == [1] * 30 + [2]
+    assert (samples.signalvals[:30] == samples.signalvals[0]).all() and (samples.signalvals[30] != samples.signalvals[0]).any()
+    # the same flow on the oracle: base run (kappa = 1, alpha = nu = 1), then the chained noise samples
+    base = oracle.estimate_signals(y[:e], 3, 200, 400, 1, sig=(0, e), kappa=1.0, alpha=1.0, nu=1.0, yreal=[y[e + 11]])
+    ssig = base["sig2"].mean() * 0.3
+    assert abs(ssig - opt.σsignal) < 1e-9 * (1 + ssig)
+    o = oracle.estimate_signals(y[:e], 3, 20, 30, 5, sig=(0, e), kappa=0.3, alpha=2.0, nu=2.0, sigma_signal=opt.σsignal,
+                                save=(e - 2, e), yreal=[y[e + 11]])
+    assert np.max(np.abs(samples.μ - o["mu"])) < 1e-9 and np.max(np.abs(samples.forecasts - o["fcast"])) < 1e-9
+    assert np.max(np.abs(samples.signalvals[::30] - o["sigvals"])) < 1e-9
+    hmc.saveresults(samples, opt, str(tmp_path / "signals_official_noise_0.3_allsignal"), hassignals=True)
+    lines = open(tmp_path / "signals_official_noise_0.3_allsignal" / "forecasts_1980-01-01.csv").read().splitlines()
+    assert lines[0] == "date,signalid,forecast_12,forecast_error_12,signal_1,signal_2" and len(lines) == 151
+    assert lines[1].startswith("1980-01-01,1,") and lines[-1].startswith("1980-01-01,5,")
+
+
+@pytest.mark.parametrize("noise", ["0.1", "0.6"])
+def test_gpu_signal_path_vs_reference_dispersion_outputs(hmclib, inflation, noise):
+    """The GPU chain against the reference's committed allsignal dispersion outputs (see the oracle test of the
+    same name for what the fixture holds): 100 noise samples x (2000 + 6000) sweeps."""
+    import csv
+    y, dates = inflation
+    dd = [dt.date.fromisoformat(d) for d in dates]
+    path = os.path.join(os.path.dirname(__file__), "golden", "signals_noise_%s_allsignal_forecasts_dispersion.csv" % noise)
+    fx = {k: float(v) for k, v in next(r for r in csv.DictReader(open(path)) if r["date"] == "1980-01-01").items() if k != "date"}
+    e, ns, n = 121, 100, 6000
+    opt = hmc.estopt(y, dd, sampleRange=range(1, e + 1), signalRange=range(1, e + 1), signalSave=range(e - 1, e + 1),
+                     endIndex=e, horizons=[12], D=3, signalburnin=2000, signalNrun=n, noiseSamples=ns, noise=float(noise),
+                     σsignal=0.5 * (fx["signal_1_std"] + fx["signal_2_std"]))
+    s = hmc.estimatesignals(opt)
+    f = s.forecasts[:, 0].reshape(ns, n).mean(axis=1)
+    se = np.hypot(f.std(ddof=1) / 10.0, fx["forecast_12_std"] / 10.0)
+    assert abs(f.mean() - fx["forecast_12_mean"]) < 4 * se + 0.02, (f.mean(), fx["forecast_12_mean"])
+    assert 0.7 < f.std(ddof=1) / fx["forecast_12_std"] < 1.45

@@ -78,3 +78,71 @@ def test_smoother_output(oracle, inflation):
     sm = r["pi_smooth"]                       # (nrun, T, K)
     np.testing.assert_allclose(sm.sum(axis=2), 1.0, atol=1e-9)
     np.testing.assert_allclose(sm[:, -1, :], r["pi_end"], atol=0)     # pib[end,:] = pif[end,:] (src/Hmc.jl:448)
+
+
+def _dispersion_row(noise, date):
+    import csv, os
+    path = os.path.join(os.path.dirname(__file__), "golden", "signals_noise_%s_allsignal_forecasts_dispersion.csv" % noise)
+    for r in csv.DictReader(open(path)):
+        if r["date"] == date:
+            return {k: float(v) for k, v in r.items() if k != "date"}
+    raise KeyError(date)
+
+
+@pytest.mark.parametrize("noise", ["0.1", "0.3", "0.6"])
+def test_signal_path_vs_reference_dispersion_outputs(oracle, inflation, noise):
+    """estimatesignals! (src/Hmc.jl:868-914) in the committed "allsignal" experiment (code/run_hmm.jl:158-175:
+    signalRange = the whole window, signalSave = the last two points, noiseSamples = 100).  The reference's
+    data/output/signals_official_noise_*_allsignal/forecasts_dispersion.csv holds, per end date, the mean and
+    the standard deviation ACROSS the 100 noise samples of each sample's mean forecast, and of the two saved
+    noisy signal values.  sigma_signal is taken from the fixture itself (the std of the saved signals is
+    sigma_signal by construction, :892): upstream derives it from mean(sigma draws) of a base run, a
+    heavy-tailed quantity (an empty state draws its variance from InvGamma(1, b), which has no mean) that cannot
+    be regenerated without Julia's RNG stream."""
+    y, dates = inflation
+    idx = 121
+    assert dates[idx - 1] == "1980-01-01"
+    fx = _dispersion_row(noise, "1980-01-01")
+    ssig = 0.5 * (fx["signal_1_std"] + fx["signal_2_std"])
+    ns, n = 60, 3000
+    r = oracle.estimate_signals(y[:idx], 3, 1000, n, ns, sig=(0, idx), kappa=float(noise), alpha=2.0, nu=2.0,
+                                sigma_signal=ssig, save=(idx - 2, idx), yreal=[y[idx + 11]])
+    assert r["status"] == 0
+    f = r["fcast"][:, 0].reshape(ns, n).mean(axis=1)             # per-sample mean forecast = one row of *_summary.csv
+    se = np.hypot(f.std(ddof=1) / np.sqrt(ns), fx["forecast_12_std"] / 10.0)
+    assert abs(f.mean() - fx["forecast_12_mean"]) < 4 * se + 0.02, (f.mean(), fx["forecast_12_mean"], se)
+    assert 0.6 < f.std(ddof=1) / fx["forecast_12_std"] < 1.6
+    e = r["fcast"][:, 1].reshape(ns, n).mean(axis=1)
+    assert abs(e.mean() - fx["forecast_error_12_mean"]) < 4 * se + 0.02
+    sv = r["sigvals"]
+    assert sv.shape == (ns, 2)
+    assert abs(sv[:, 0].mean() - fx["signal_1_mean"]) < 4 * ssig / np.sqrt(ns) + 4 * fx["signal_1_std"] / 10
+    assert 0.7 < sv[:, 0].std(ddof=1) / ssig < 1.3
+
+
+def test_signal_model_two_population_update(oracle):
+    """Teacher-forced conjugate update with an observation set and a signal set (src/Hmc.jl:254-335):
+    exact conditional posterior means given X, including the reference's asymmetries (quirk 4: the signal sum
+    enters the mean unscaled, :331, while the variance term is scaled by 1/(1+kappa), :314)."""
+    rng = np.random.default_rng(8)
+    T, K, kap = 400, 2, 0.5
+    X = rng.integers(0, K, T)
+    mus = np.array([-2.0, 3.0]); Y = mus[X] + rng.normal(0, 0.8, T)
+    sb = 300
+    draws = [oracle.estimate_signals(Y, K, 0, 1, 1, sig=(sb, T), kappa=kap, alpha=2.0, nu=2.0, horizons=(), seed=s, x_init=X)
+             for s in range(400)]
+    m = np.mean([d["mu"][0] for d in draws], axis=0)
+    v = np.mean([d["sig2"][0] for d in draws], axis=0)
+    xi = Y.mean()
+    for i in range(K):
+        yo = Y[:sb][X[:sb] == i]; ys = Y[sb:][X[sb:] == i]
+        Ni, Mi = len(yo), len(ys)
+        Neff = Ni + Mi / (1 + kap)
+        a = 2.0 + 0.5 * Ni + 0.5 * Mi
+        tot = (yo.sum() + ys.sum()) / (Ni + Mi)
+        b = 1.0 + 0.5 * ((yo - yo.mean()) ** 2).sum() + 0.5 / (1 + kap) * ((ys - ys.mean()) ** 2).sum() \
+            + 0.5 * Neff * 2.0 / (Neff + 2.0) * (tot - xi) ** 2
+        e_sig = b / (a - 1.0)
+        assert abs(v[i] - e_sig) < 5 * e_sig / np.sqrt(a - 2.0) / np.sqrt(400), (i, v[i], e_sig)
+        e_mu = (yo.sum() + ys.sum() + 2.0 * xi) / (Neff + 2.0)
+        assert abs(m[i] - e_mu) < 5 * np.sqrt(e_sig / (Neff + 2.0)) / np.sqrt(400), (i, m[i], e_mu)
