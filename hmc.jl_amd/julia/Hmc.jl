@@ -10,6 +10,9 @@
 # has a `julia` binary.  The tested host layer with the same surface is hmc.jl_amd/hmc.py; the C ABI
 # it shares with this file is what the parity tests exercise.
 #
+# Not wired here yet (available through the C ABI and the Python host layer): the signal Monte-Carlo path
+# (estimatesignals!, hmcg_extras.sig_range/...), explicit window ids, checkpoint/resume.
+#
 # Reference lines mirrored: estopt src/Hmc.jl:17-73, accessors :85-107, makedate :573-582,
 # forecast :658-667, basicsave/saveresults :707-748, estimatemodel :850-865.
 module Hmc
