@@ -46,6 +46,9 @@ struct hmcg_config
     sweep_count::Int32
     alpha::Float64
     nu::Float64
+    kappa::Float64
+    n_samples::Int32
+    reserved1::Int32
 end
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))
@@ -129,7 +132,8 @@ function estimatewindows(opts::Vector{estopt}; device::Integer=0, keepdraws::Boo
     end
     hz = ntuple(i -> i <= H ? Int32(o.horizons[i]) : Int32(0), HMCG_MAXH)
     cfg = Ref(hmcg_config(Int32(sizeof(hmcg_config)), W, K, ldY, Int32(maximum(Ts)), o.burnin, nrun, H, hz,
-                          UInt64(o.seed), UInt32(0), Int32(device), Int32(0), Int32(0), Int32(0), Int32(0), 0.0, 0.0))
+                          UInt64(o.seed), UInt32(0), Int32(device), Int32(0), Int32(0), Int32(0), Int32(0), 0.0, 0.0,
+                          0.0, Int32(0), Int32(0)))
     NS = 3K + K * K + 2H
     μ = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
     σ = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
