@@ -44,10 +44,9 @@ struct KernelParams {
     const double* Y;        // [W][ldY]
     const int32_t* T;       // [W]
     const double* yreal;    // [W][H] or null
-    int32_t ldY, W, H, nrun;
+    int32_t ldY, W, H;
     int32_t sweep_begin;    // global index of first sweep of this launch
     int32_t sweep_end;      // one past the last sweep of this launch
-    int32_t keep_from;      // global sweep index of the first kept draw (= burnin)
     int32_t resume;         // 1: load chain from xstate, 0: makeParams init
     int32_t final_launch;   // 1: write summary
     int32_t horizons[HMCG_MAXH];
@@ -109,6 +108,25 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 {
     const uint64_t x = ((uint64_t)a << 21) | (uint64_t)(b >> 11);
     return (double)x * 0x1.0p-53;
+}
+
+// exp(x), x <= 0, with a 32-entry table of 2^(j/32) (held in LDS): x = (32 e + j) ln2/32 + r, |r| <= ln2/64,
+// exp(r) by a degree-6 Taylor polynomial (truncation 4e-18), result 2^e * tab[j] * poly: ~1 ulp.
+__device__ __forceinline__ double exp_tab(double x, const double* tab)
+{
+    x = fmax(x, -746.0);
+    const double n = rint(x * 46.166241308446828);            // 32 / ln 2
+    double r = fma(-n, 2.1660849386535119e-02, x);            // ln2/32 high part (32 significant bits)
+    r = fma(-n, 5.9631716539705866e-12, r);                   // ln2/32 low part
+    const int ni = (int)n;
+    const double tj = tab[ni & 31];
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(tj * p, ni >> 5);
 }
 
 // 1/x: hardware reciprocal + one Newton step (<= 1 ulp; within the parity tolerance)
@@ -517,6 +535,7 @@ struct SweepShared {
     double bred[NW];              // generic block reductions (init)
     double med[2];
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
+    double exptab[32];            // 2^(j/32), j = 0..31
 };
 
 template <int NW>
@@ -609,6 +628,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         return;
     }
 
+    if (tid < 32) sh.exptab[tid] = exp2((double)tid * (1.0 / 32.0));     // correctly rounded enough (OCML exp2, < 1 ulp)
     // ---- load the window's observations (once per launch) ----
     double y[L];
     int x[L];
@@ -1150,7 +1170,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 const double mu = m + sdev * rb.z[role];                         // :334
                 const double isd = rcp_fast(sd);
                 th.mu[role] = mu; th.sig2[role] = sig2;
-                th.isd[role] = isd; th.coef[role] = INVSQRT2PI * isd;
+                th.isd[role] = isd * 0.70710678118654752440; th.coef[role] = INVSQRT2PI * isd;
                 th.rho[role] = rb.rho[role];                                     // :355
             } else if (is_g) {
                 const int e = role - K;
@@ -1216,14 +1236,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             unsigned hm = 0;
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                double z = (y[l] - mu[s]) * isd[s];
+                double z = (y[l] - mu[s]) * isd[s];          // isd holds 1/(sd*sqrt(2)): exp(-z^2) = exp(-((y-mu)/sd)^2/2)
                 double cf = coef[s];
                 if constexpr (SIG) {                 // signal positions: sd scaled by (1 + kappa) (:382, quirk 4)
                     const bool issig = (t0 + l) >= sb && (t0 + l) < se;
                     z = issig ? z * kfac : z;
                     cf = issig ? cf * kfac : cf;
                 }
-                f[l][s] = exp_fast(-0.5 * (z * z)) * cf;
+                f[l][s] = exp_tab(-(z * z), sh.exptab) * cf;
                 hm = max(hm, (unsigned)__double2hiint(f[l][s]));
             }
             if (hm < 0x01A56E1Fu) {                  // largest pdf < 1e-300 (high word of 1e-300 is 0x01A56E1F)

@@ -166,7 +166,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     (void)vK;
     hmcg::KernelParams p{};
     p.Y = dY; p.T = dT; p.yreal = dyreal;
-    p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H; p.nrun = cfg->nrun;
+    p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H;
     p.sweep_begin = cfg->sweep_base;
     p.per_sample = cfg->burnin + cfg->nrun;
     p.burnin_s = cfg->burnin; p.nrun_s = cfg->nrun; p.n_samples = n_samples; p.nd = n_samples * cfg->nrun;
@@ -174,7 +174,6 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     const int total_sweeps = n_samples * (cfg->burnin + cfg->nrun);
     p.sweep_end = total_sweeps;
     if (cfg->sweep_count > 0 && cfg->sweep_base + cfg->sweep_count < p.sweep_end) p.sweep_end = cfg->sweep_base + cfg->sweep_count;
-    p.keep_from = cfg->burnin;
     p.resume = resume ? 1 : 0;
     p.final_launch = (p.sweep_end == total_sweeps) ? 1 : 0;
     p.kappa = cfg->kappa;
