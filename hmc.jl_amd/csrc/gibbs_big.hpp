@@ -52,7 +52,8 @@ struct BigShared {
 template <int K, int NT>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
-    static_assert(K >= 5 && K <= 8, "large-K kernel (4-bit map entries: K <= 8)");
+    static_assert(K >= 2 && K <= 8, "4-bit map entries: K <= 8 (K <= 4 normally runs on the register-resident kernel; this one\n"
+                                    "also serves small K when the window is too long for it)");
     constexpr int NW = NT / 64;
     constexpr int KK = K * K;
     constexpr int NG = K + KK;

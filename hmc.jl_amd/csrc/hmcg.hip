@@ -93,6 +93,8 @@ struct BigVariant {
     BigKernelFn fn;
 };
 const BigVariant g_big_variants[] = {
+    { 2, 256, hmcg::gibbs_sweeps_kernel_big<2, 256> }, { 3, 256, hmcg::gibbs_sweeps_kernel_big<3, 256> },
+    { 4, 256, hmcg::gibbs_sweeps_kernel_big<4, 256> },
     { 5, 256, hmcg::gibbs_sweeps_kernel_big<5, 256> }, { 6, 256, hmcg::gibbs_sweeps_kernel_big<6, 256> },
     { 7, 256, hmcg::gibbs_sweeps_kernel_big<7, 256> }, { 8, 256, hmcg::gibbs_sweeps_kernel_big<8, 256> },
 };
@@ -147,16 +149,14 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     const BigVariant* bv = nullptr;
     int bigL = 0;
     size_t dyn = 0;
-    if (cfg->K >= 5) {
+    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig);
+    if (!v && !use_sig) {            // large K, or a window too long for the register-resident variants
         for (const BigVariant& b : g_big_variants) if (b.K == cfg->K) bv = &b;
         if (bv) {
             bigL = (maxT + bv->NT - 1) / bv->NT;
             dyn = (size_t)bv->NT * bigL * (8 + 8 + 4 + 1) + 16;
             if (dyn > BIG_MAX_DYN_LDS || (cfg->threads_per_window != 0 && cfg->threads_per_window != bv->NT)) bv = nullptr;
         }
-    } else {
-        v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig);
-        if (v) dyn = 0;
     }
     if (!v && !bv) {
         set_err("no kernel for K=%d max_T=%d threads_per_window=%d", cfg->K, maxT, cfg->threads_per_window);

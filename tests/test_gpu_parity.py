@@ -69,6 +69,13 @@ def test_large_k_kernel(hmclib, oracle, K):
     check_against_oracle(oracle, Y, Tw, K, 3, 10, (1, 12), fut[:, [0, 11]])
 
 
+def test_long_window_small_k_uses_lds_resident_kernel(hmclib, oracle):
+    """K=3 with T beyond the register-resident variants (4096): served by the LDS-resident kernel."""
+    Y, Tw, fut = synth.generate_panel(2, 5000, 3)
+    g = check_against_oracle(oracle, Y, Tw, 3, 2, 6, (12,), fut[:, 11:12])
+    assert g["steps_per_thread"] == 20 and g["lds_bytes"] > 100000
+
+
 def test_cfg4_shape_8_states_T5000(hmclib, oracle):
     """BASELINE configs[3] shape (8-state, T=5000) on a few windows, fewer draws; full-size properties."""
     K, T, W = 8, 5000, 3
