@@ -68,6 +68,9 @@ struct KernelParams {
     const double* sigma_signal;     // [W] sd of the noise added to the signal positions of each sample
     double* sigvals;                // [W][n_samples][nsave_ld]
     int32_t nsave_ld;
+    // smoothed probabilities (backwardupdate_P!, src/Hmc.jl:442-457): running sum over the kept draws of
+    // P(X_t | Y_1:T, theta) in SORTED labels, [W][ldY][K]; divided by nd at the final launch
+    double* pi_smooth_mean;
 };
 
 // index of the kept draw produced by global sweep g, or -1 during burn-in
@@ -383,6 +386,28 @@ __device__ __forceinline__ void scan_level(double (&Q)[K * K])
     for (int i = 0; i < K * K; ++i) Q[i] = N[i];
 }
 
+// one level of the inclusive scan with the product order flipped: Q <- Q * (Q of the source lane)
+template <int K, int CTRL, int RMASK>
+__device__ __forceinline__ void scan_level_rev(double (&Q)[K * K])
+{
+    double O[K * K], N[K * K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int s = 0; s < K; ++s) O[r * K + s] = dpp_f64<CTRL, RMASK>((r == s) ? 1.0 : 0.0, Q[r * K + s]);
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            double acc = Q[r * K] * O[s];
+#pragma unroll
+            for (int k = 1; k < K; ++k) acc = fma(Q[r * K + k], O[k * K + s], acc);
+            N[r * K + s] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) Q[i] = N[i];
+}
+
 // Same, for large K: one source row at a time (K doubles live instead of K*K)
 template <int K, int CTRL, int RMASK>
 __device__ __forceinline__ void scan_level_rowwise(double (&Q)[K * K], double (&N)[K * K])
@@ -604,7 +629,7 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 
 // ------------------------------------------------------------- kernel ----
 
-template <int K, int L, int NT, bool SIG = false>
+template <int K, int L, int NT, bool SIG = false, bool SMOOTH = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 {
     static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter-draw roles fit one wave");
@@ -1043,6 +1068,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     if (p.sweep_begin < p.sweep_end && shadow_wave == 0) job_prep(p.sweep_begin);
 
     double pf[L][K];     // unsorted filtered probabilities of this thread's steps
+    double sm_acc[SMOOTH ? L : 1][K];   // running sums of the smoothed probabilities of this thread's steps
+    if constexpr (SMOOTH) {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+                sm_acc[l][q] = (p.resume && p.pi_smooth_mean && t0 + l < T) ? p.pi_smooth_mean[((size_t)w * p.ldY + t0 + l) * K + q] : 0.0;
+    }
+    (void)sm_acc;
 #ifdef HMCG_STAMPS
     for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
     stamp_prev = __builtin_amdgcn_s_memtime();
@@ -1265,7 +1299,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int r = 0; r < K; ++r)
 #pragma unroll
-            for (int s = 0; s < K; ++s) Q[r * K + s] = A[r][s] * f[0][s];
+            for (int s = 0; s < K; ++s) {
+                Q[r * K + s] = A[r][s] * f[0][s];
+                if constexpr (SMOOTH) Q[r * K + s] = (t0 < T) ? Q[r * K + s] : ((r == s) ? 1.0 : 0.0);
+            }
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             double N[KK];
@@ -1278,10 +1315,22 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                     for (int k = 1; k < K; ++k) acc = fma(Q[r * K + k], A[k][s], acc);
                     N[r * K + s] = acc * f[l][s];
                 }
+            if constexpr (SMOOTH) {                  // the suffix products must not see padded steps
+                const bool v = (t0 + l) < T;
 #pragma unroll
-            for (int i = 0; i < KK; ++i) Q[i] = N[i];
+                for (int i = 0; i < KK; ++i) Q[i] = v ? N[i] : Q[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < KK; ++i) Q[i] = N[i];
+            }
         }
         rescale_pow2<KK>(Q);
+        double Qloc[SMOOTH ? KK : 1];                // this thread's own product, for the backward (suffix) scan
+        if constexpr (SMOOTH) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i) Qloc[i] = Q[i];
+        }
+        (void)Qloc;
         STAMP(4);
         // inclusive scan over the wave (earlier lanes multiply on the left); the per-step scaling
         // keeps every factor's largest entry in [0.5,1), so rescaling every other level is ample
@@ -1366,6 +1415,85 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                     for (int s = 0; s < K; ++s) th.pi_end[s] = pf[l][s];
                     sh.ulast = ux[l];
                 }
+        }
+        if constexpr (SMOOTH) {
+            // ---- backwardupdate_P! (src/Hmc.jl:442-457) as the beta recursion b_{t-1} = A (f_t o b_t), b_{T-1} = 1:
+            // pib[t,:] ~ pif[t,:] o b_t.  b at the end of a thread's chunk = (product of the later chunks' matrices) * 1:
+            // a SUFFIX scan of the local products -- done as a prefix scan on lane-reversed data with the
+            // multiplication order flipped -- then the later waves' totals (the forward wave totals, already in LDS).
+            double R[KK];
+#pragma unroll
+            for (int i = 0; i < KK; ++i) R[i] = __shfl(Qloc[i], 63 - lane, 64);
+            scan_level_rev<K, DPP_ROW_SHR1, 0xF>(R);
+            scan_level_rev<K, DPP_ROW_SHR2, 0xF>(R);
+            rescale_pow2<KK>(R);
+            scan_level_rev<K, DPP_ROW_SHR4, 0xF>(R);
+            scan_level_rev<K, DPP_ROW_SHR8, 0xF>(R);
+            rescale_pow2<KK>(R);
+            scan_level_rev<K, DPP_ROW_BCAST15, 0xA>(R);
+            scan_level_rev<K, DPP_ROW_BCAST31, 0xC>(R);
+            rescale_pow2<KK>(R);
+            // vector entering this wave from the later ones: W_{wave+1} (W_{wave+2} (... 1))
+            double bw[K];
+#pragma unroll
+            for (int r = 0; r < K; ++r) bw[r] = 1.0;
+#pragma unroll
+            for (int ww = NW - 1; ww >= 1; --ww) {
+                double nb[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) acc = fma(sh.wtot[ww][r * K + c], bw[c], acc);
+                    nb[r] = acc;
+                }
+                rescale_pow2<K>(nb);
+#pragma unroll
+                for (int r = 0; r < K; ++r) bw[r] = (ww > wave) ? nb[r] : bw[r];
+            }
+            // exclusive suffix of lane j = inclusive result held by reversed lane (63-j)-1, i.e. physical lane 62-j
+            double b[K];
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const double e = __shfl(R[r * K + c], lane < 63 ? 62 - lane : 0, 64);
+                    acc = fma((lane < 63) ? e : ((r == c) ? 1.0 : 0.0), bw[c], acc);
+                }
+                b[r] = acc;
+            }
+            rescale_pow2<K>(b);
+            const bool kept = kept_index(p, sweep) >= 0;
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                if (t0 + l < T) {
+                    double g[K], tot = 0.0;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) { g[s] = pf[l][s] * b[s]; tot += g[s]; }
+                    const double inv = rcp_fast(tot);
+                    if (kept) {
+#pragma unroll
+                        for (int q = 0; q < K; ++q) {
+                            double gq = 0.0;
+#pragma unroll
+                            for (int s = 0; s < K; ++s) gq = (order[q] == s) ? g[s] : gq;
+                            sm_acc[l][q] = fma(gq, inv, sm_acc[l][q]);      // sorted labels (:513)
+                        }
+                    }
+                    double nb[K];
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) acc = fma(A[r][s] * f[l][s], b[s], acc);
+                        nb[r] = acc;
+                    }
+                    rescale_pow2<K>(nb);
+#pragma unroll
+                    for (int r = 0; r < K; ++r) b[r] = nb[r];
+                }
+            }
         }
         STAMP(7);
         __syncthreads();                                                     // Bd
@@ -1473,6 +1601,16 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             if (t0 + l < T)
 #pragma unroll
                 for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t0 + l) * K + s] = pf[l][s];
+    }
+    if constexpr (SMOOTH) {
+        if (p.pi_smooth_mean) {
+            const double sc = (p.final_launch && p.nd > 0) ? 1.0 / (double)p.nd : 1.0;
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if (t0 + l < T)
+#pragma unroll
+                    for (int q = 0; q < K; ++q) p.pi_smooth_mean[((size_t)w * p.ldY + t0 + l) * K + q] = sm_acc[l][q] * sc;
+        }
     }
     if (orole >= 0) {
         if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;

@@ -71,11 +71,12 @@ using KernelFn = void (*)(const hmcg::KernelParams);
 struct Variant {
     int K, L, NT;
     KernelFn fn;
-    bool sig;
+    bool sig, smooth;
 };
 
-#define HMCG_VARIANT(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, false>, false }
-#define HMCG_VARIANT_SIG(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, true>, true }
+#define HMCG_VARIANT(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, false, false>, false, false }
+#define HMCG_VARIANT_SIG(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, true, false>, true, false }
+#define HMCG_VARIANT_SMOOTH(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, false, true>, false, true }
 const Variant g_variants[] = {
     HMCG_VARIANT(2, 1, 256), HMCG_VARIANT(2, 2, 256), HMCG_VARIANT(2, 4, 256), HMCG_VARIANT(2, 8, 256),
     HMCG_VARIANT(3, 1, 256), HMCG_VARIANT(3, 2, 256), HMCG_VARIANT(3, 4, 256), HMCG_VARIANT(3, 8, 256),
@@ -85,6 +86,9 @@ const Variant g_variants[] = {
     // signal Monte-Carlo path (estimatesignals!): two-population statistics, per-step emission scale
     HMCG_VARIANT_SIG(2, 1, 256), HMCG_VARIANT_SIG(2, 2, 256), HMCG_VARIANT_SIG(2, 4, 256),
     HMCG_VARIANT_SIG(3, 1, 256), HMCG_VARIANT_SIG(3, 2, 256), HMCG_VARIANT_SIG(3, 4, 256), HMCG_VARIANT_SIG(3, 8, 256),
+    // with the smoothed-probability output (full backward pass every sweep)
+    HMCG_VARIANT_SMOOTH(2, 1, 256), HMCG_VARIANT_SMOOTH(2, 2, 256), HMCG_VARIANT_SMOOTH(2, 4, 256),
+    HMCG_VARIANT_SMOOTH(3, 1, 256), HMCG_VARIANT_SMOOTH(3, 2, 256), HMCG_VARIANT_SMOOTH(3, 4, 256), HMCG_VARIANT_SMOOTH(3, 8, 256),
 };
 
 using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
@@ -100,12 +104,12 @@ const BigVariant g_big_variants[] = {
 };
 constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
-const Variant* pick_variant(int K, int maxT, int nt_req, bool sig)
+const Variant* pick_variant(int K, int maxT, int nt_req, bool sig, bool smooth)
 {
     const int nt = nt_req > 0 ? nt_req : 256;
     const Variant* best = nullptr;
     for (const Variant& v : g_variants) {
-        if (v.K != K || v.NT != nt || v.L * v.NT < maxT || v.sig != sig) continue;
+        if (v.K != K || v.NT != nt || v.L * v.NT < maxT || v.sig != sig || v.smooth != smooth) continue;
         if (!best || v.L < best->L) best = &v;
     }
     return best;
@@ -149,8 +153,10 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     const BigVariant* bv = nullptr;
     int bigL = 0;
     size_t dyn = 0;
-    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig);
-    if (!v && !use_sig) {            // large K, or a window too long for the register-resident variants
+    const bool use_smooth = ex && ex->pi_smooth_mean != nullptr;
+    if (use_smooth && use_sig) { set_err("pi_smooth_mean is not available on the signal path"); return HMCG_E_UNSUPPORTED; }
+    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth);
+    if (!v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
         for (const BigVariant& b : g_big_variants) if (b.K == cfg->K) bv = &b;
         if (bv) {
             bigL = (maxT + bv->NT - 1) / bv->NT;
@@ -177,6 +183,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     p.resume = resume ? 1 : 0;
     p.final_launch = (p.sweep_end == total_sweeps) ? 1 : 0;
     p.kappa = cfg->kappa;
+    if (ex) p.pi_smooth_mean = ex->pi_smooth_mean;
     if (ex) { p.sig_range = ex->sig_range; p.save_range = ex->save_range; p.sigma_signal = ex->sigma_signal; p.sigvals = ex->sigvals; p.nsave_ld = ex->nsave_ld; }
     for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.window_base = cfg->window_base;
@@ -319,7 +326,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     DevBuf<uint8_t> dxs;
     DevBuf<uint32_t> dwid;
     DevBuf<int32_t> dsr, dsv;
-    DevBuf<double> dss, dsvals;
+    DevBuf<double> dss, dsvals, dsm;
 #define ALLOC(buf, n) do { if ((buf).alloc(n) != 0) { set_err("hipMalloc of %zu elements failed", (size_t)(n)); return HMCG_E_NOMEM; } } while (0)
     ALLOC(dY, W * ld); ALLOC(dT, W); ALLOC(dst, W);
     HIP_TRY(hipMemcpyAsync(dY.p, Y, sizeof(double) * W * ld, hipMemcpyHostToDevice, s));
@@ -356,6 +363,12 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
             HIP_TRY(hipMemsetAsync(dsvals.p, 0, sizeof(double) * W * nsmp * (size_t)extras->nsave_ld, s));
             dex.sigvals = dsvals.p; dex.nsave_ld = extras->nsave_ld;
         }
+        if (extras->pi_smooth_mean) {
+            ALLOC(dsm, W * ld * K);
+            if (resume) HIP_TRY(hipMemcpyAsync(dsm.p, extras->pi_smooth_mean, sizeof(double) * W * ld * K, hipMemcpyHostToDevice, s));
+            else HIP_TRY(hipMemsetAsync(dsm.p, 0, sizeof(double) * W * ld * K, s));
+            dex.pi_smooth_mean = dsm.p;
+        }
         if (extras->window_ids) { ALLOC(dwid, W); HIP_TRY(hipMemcpyAsync(dwid.p, extras->window_ids, sizeof(uint32_t) * W, hipMemcpyHostToDevice, s)); dex.window_ids = dwid.p; }
         if (extras->sumacc) {
             ALLOC(dacc, W * (NS + K));
@@ -378,6 +391,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     D2H(status, dst.p, sizeof(int32_t) * W);
     if (extras) {
         D2H(extras->sigvals, dsvals.p, sizeof(double) * W * nsmp * (size_t)(extras->nsave_ld > 0 ? extras->nsave_ld : 0));
+        D2H(extras->pi_smooth_mean, dsm.p, sizeof(double) * W * ld * K);
         D2H(extras->x_final, dxf.p, sizeof(int32_t) * W * ld);
         D2H(extras->pif_final, dpif.p, sizeof(double) * W * ld * K);
         D2H(extras->xstate, dxs.p, W * ld);

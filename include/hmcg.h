@@ -124,6 +124,10 @@ typedef struct hmcg_extras {
     double* sigvals;            /* [W][n_samples][nsave_ld] Yfake[signalSave] of every noise sample (:904) */
     int32_t nsave_ld;
     int32_t reserved2;
+    double* pi_smooth_mean;     /* [W][ldY][K] optional: mean over the kept draws of the SMOOTHED probabilities
+                                   P(X_t | Y_1:T, theta) in sorted labels = the draw-average of the reference's
+                                   samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  K <= 3 variants;
+                                   costs about 20 % more per sweep.  NULL: only pib[end,:] is produced */
 } hmcg_extras;
 
 typedef struct hmcg_timing {

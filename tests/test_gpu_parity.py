@@ -135,6 +135,24 @@ def test_signal_path_partial_signal_synthetic(hmclib, oracle):
         check_signals_against_oracle(oracle, Y, Tw, K, 3, 8, 3, sig, save, 0.6, 2.0, 2.0, np.array([0.5, 1.0, 0.2]), fut[:, 11:12])
 
 
+@pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64, 5]), (2, [300, 2, 129])])
+def test_smoothed_probabilities_mean(hmclib, oracle, K, lens):
+    """Optional output: the draw-average of the smoothed probabilities pib[:, t, :] (backwardupdate_P!,
+    src/Hmc.jl:442-457, sorted labels :513).  The GPU runs the beta recursion as a suffix scan; the oracle
+    runs the reference's Pb recursion.  Same bar: 1e-9 on probabilities."""
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
+    g = _lib.estimate_batch_host(Y, Tw, K, 3, 12, (12,), fut[:, 11:12], want_state=True, want_smooth=True)
+    for w in range(len(lens)):
+        o = oracle.estimate_window(Y[w, :Tw[w]], K, 3, 12, (12,), fut[w, 11:12], window_id=w, want_smooth=True)
+        assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"])
+        ref = o["pi_smooth"].mean(axis=0)                       # (T, K)
+        got = g["pi_smooth_mean"][w, :Tw[w]]
+        assert np.max(np.abs(got - ref)) < TOL, (w, np.max(np.abs(got - ref)))
+        assert np.max(np.abs(got.sum(axis=1) - 1)) < 1e-12
+        assert np.max(np.abs(got[-1] - g["pi_end"][w].mean(axis=1))) < 1e-12       # pib[end,:] = pif[end,:] (:448)
+        assert close(g["mu"][w].T, o["mu"]) < TOL
+
+
 def test_mixed_lengths_in_one_call(hmclib, oracle):
     lens = [1000, 17, 400, 2]
     Y, Tw, fut = synth.generate_panel(4, 1000, 3, ragged=lens)
