@@ -152,8 +152,12 @@ def _unpack(res, w, nrun, K, H, obsdate):
     return Samples(mu, sig, pe[:, None, :], A, fc, [obsdate] * nrun, int(res["status"][w]))
 
 
-def estimatemodel(opt, device=0):
+def estimatemodel(opt, device=0, smooth=False):
     """Hmc.estimatemodel(opt) (src/Hmc.jl:850-865) on the GPU.
+
+    smooth=True additionally runs the full backward pass (backwardupdate_P!, :442-457) every sweep and
+    returns, as `samples.πb_mean` (N, D), the mean over the kept draws of the smoothed probabilities
+    `samples.πb[:, t, :]` -- what smoothStates/forecastinsample average upstream (:649-654, :696).
 
     Returns Samples(μ[Nrun,D], σ[Nrun,D] (variances), πb[Nrun,1,D], A[Nrun,D,D],
     forecasts[Nrun,2H], obsdates).  πb keeps only the window's last time step -- the
@@ -170,8 +174,21 @@ def estimatemodel(opt, device=0):
         kw = dict(sig_range=[sig], save_range=[sv], sigma_signal=[0.0], kappa=1.0, n_samples=1)
     res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.burnin, opt.Nrun, tuple(opt.horizons),
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
-                                   device=device, **kw)
-    return _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
+                                   device=device, want_smooth=smooth, **kw)
+    s = _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
+    if smooth:
+        s.πb_mean = res["pi_smooth_mean"][0, :len(Y)]
+    return s
+
+
+def savesmoothresults(πb_mean, dates, dir):
+    """`smoothed_state_probs.csv` in the layout of savesmoothresults (src/Hmc.jl:750-758): Date, state_1.."""
+    os.makedirs(dir, exist_ok=True)
+    D = πb_mean.shape[1]
+    with open(os.path.join(dir, "smoothed_state_probs.csv"), "w") as f:
+        f.write(",".join(["Date"] + ["state_%d" % i for i in range(1, D + 1)]) + "\n")
+        for d, row in zip(dates, πb_mean):
+            f.write(",".join([str(d)] + [_fmt(v) for v in row]) + "\n")
 
 
 def estimatesignals(opt, device=0):

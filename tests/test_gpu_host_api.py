@@ -98,3 +98,17 @@ def test_gpu_signal_path_vs_reference_dispersion_outputs(hmclib, inflation, nois
     se = np.hypot(f.std(ddof=1) / 10.0, fx["forecast_12_std"] / 10.0)
     assert abs(f.mean() - fx["forecast_12_mean"]) < 4 * se + 0.02, (f.mean(), fx["forecast_12_mean"])
     assert 0.7 < f.std(ddof=1) / fx["forecast_12_std"] < 1.45
+
+
+def test_smoothed_state_probabilities_host_api(hmclib, oracle, inflation, tmp_path):
+    y, dates = inflation
+    dd = [dt.date.fromisoformat(d) for d in dates]
+    e = 200
+    opt = hmc.estopt(y, dd, sampleRange=range(1, e + 1), endIndex=e, horizons=[12], D=3, burnin=50, Nrun=100)
+    s = hmc.estimatemodel(opt, smooth=True)
+    assert s.πb_mean.shape == (e, 3) and np.max(np.abs(s.πb_mean.sum(axis=1) - 1)) < 1e-12
+    o = oracle.estimate_window(y[:e], 3, 50, 100, (12,), [y[e + 11]], want_smooth=True)
+    assert np.max(np.abs(s.πb_mean - o["pi_smooth"].mean(axis=0))) < 1e-9
+    hmc.savesmoothresults(s.πb_mean, dd[:e], str(tmp_path))
+    lines = open(tmp_path / "smoothed_state_probs.csv").read().splitlines()
+    assert lines[0] == "Date,state_1,state_2,state_3" and len(lines) == e + 1 and lines[1].startswith("1970-01-01,")

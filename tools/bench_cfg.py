@@ -7,6 +7,7 @@ from hmc_jl_amd import synth
 from hmc_jl_amd.device import DevicePanel
 K, T, W, n = (int(a) for a in sys.argv[1:5])
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+smooth = len(sys.argv) > 6 and sys.argv[6] == "smooth"
 rng = np.random.default_rng(0)
 if W * T > 300000:      # fast synthetic panel: tile a few generated windows with per-window shifts
     base, _, fut0 = synth.generate_panel(8, T, K)
@@ -16,7 +17,20 @@ if W * T > 300000:      # fast synthetic panel: tile a few generated windows wit
 else:
     Y, Tw, fut = synth.generate_panel(W, T, K)
 p = DevicePanel(Y, Tw, K, n, (12,), fut[:, 11:12])
-ms = [p.run(burnin=0) for _ in range(reps + 1)][1:]
+if smooth:
+    import ctypes as C
+    import torch
+    from hmc_jl_amd import _lib
+    sm = torch.zeros((W, T, K), dtype=torch.float64, device="cuda")
+    def run():
+        cfg = _lib.make_config(W, K, T, T, 0, n, (12,))
+        ex = _lib.Extras(); ex.struct_size = C.sizeof(_lib.Extras); ex.pi_smooth_mean = sm.data_ptr()
+        return _lib.estimate_batch_device(cfg, p.Y.data_ptr(), p.T.data_ptr(), p.yreal.data_ptr(), 0, 0, 0, 0, 0,
+                                          p.summary.data_ptr(), p.status.data_ptr(), ex, None, True).kernel_ms
+    ms = [run() for _ in range(reps + 1)][1:]
+    p.last_timing = type("T", (), dict(threads_per_window=256, steps_per_thread=(T + 255) // 256, lds_bytes=0))()
+else:
+    ms = [p.run(burnin=0) for _ in range(reps + 1)][1:]
 B = T * (8 + 16 * K + 2) + 8 * (3 * K + K * K + 2)
 k = float(np.mean(ms))
 tm = p.last_timing
