@@ -203,7 +203,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         out["status"] = np.ascontiguousarray(resume_state["status"], dtype=np.int32).copy()
         ex.xstate = out["xstate"].ctypes.data
         ex.sumacc = out["sumacc"].ctypes.data
-    cfg = make_config(W, K, ldY, int(T.max()), burnin, nrun, horizons, seed, window_base, device, flags,
+    cfg = make_config(W, K, ldY, min(int(T.max()), ldY), burnin, nrun, horizons, seed, window_base, device, flags,
                       threads_per_window, sweep_base, alpha, nu, sweep_count, kappa, n_samples)
     tm = Timing()
     rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),

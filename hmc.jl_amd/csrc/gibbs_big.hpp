@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     const int T = p.T[w];
     const int t0 = tid * L;
     int st = 0;
-    if (T < 2 || T > cap) {
+    if (T < 2 || T > cap || T > p.ldY) {
         if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
         return;
     }
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 
     if (tid < K) sh.pivot[tid] = xi;
     if (p.resume) {
-        for (int t = tid; t < cap; t += NT) xs[t] = t < T ? p.xstate[(size_t)w * p.ldY + t] : 0;
+        for (int t = tid; t < cap; t += NT) xs[t] = t < T ? (uint8_t)min((int)p.xstate[(size_t)w * p.ldY + t], K - 1) : 0;
         if (p.sumacc && tid < K) sh.pivot[tid] = p.sumacc[(size_t)w * NCK + NS + tid];
     } else if (p.x_init) {
-        for (int t = tid; t < cap; t += NT) xs[t] = t < T ? (uint8_t)p.x_init[(size_t)w * p.ldY + t] : 0;
+        for (int t = tid; t < cap; t += NT) xs[t] = t < T ? (uint8_t)min(max(p.x_init[(size_t)w * p.ldY + t], 0), K - 1) : 0;   // caller data: clamp
     } else {
         // makeParams (src/Hmc.jl:161-195): see the small-K kernel for the nearest-mean rule
         double lmin = 1.0e308, lmax = -1.0e308;

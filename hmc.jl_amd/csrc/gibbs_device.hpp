@@ -648,7 +648,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     const int owner = (T - 1) / L, l_last = (T - 1) % L;   // thread and slot that hold the last time step
     int st = 0;
 
-    if (T < 2 || T > NT * L) {           // uniform per block
+    if (T < 2 || T > NT * L || T > p.ldY) {   // uniform per block
         if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
         return;
     }
@@ -695,14 +695,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     const int NCK = 3 * K + K * K + 2 * p.H + K;      // checkpoint block: summary sums + pivots
     if (p.resume) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (t0 + l < T) x[l] = p.xstate[(size_t)w * p.ldY + t0 + l];
+        for (int l = 0; l < L; ++l) if (t0 + l < T) x[l] = min((int)p.xstate[(size_t)w * p.ldY + t0 + l], K - 1);
         if (p.sumacc) {
 #pragma unroll
             for (int k = 0; k < K; ++k) pivot[k] = p.sumacc[(size_t)w * NCK + (NCK - K) + k];
         }
     } else if (p.x_init) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) if (t0 + l < T) x[l] = p.x_init[(size_t)w * p.ldY + t0 + l];
+        for (int l = 0; l < L; ++l) if (t0 + l < T) x[l] = min(max(p.x_init[(size_t)w * p.ldY + t0 + l], 0), K - 1);   // caller data: clamp
     } else {
         // ---- makeParams (src/Hmc.jl:161-195): mu spread around the median, X = argmax pdf.
         // The initial "sigma" (= std(Y), :177) is the same for every state and is overwritten by the

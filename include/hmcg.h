@@ -67,7 +67,7 @@ extern "C" {
                                     normaliser was replaced by the uniform law (reference would produce NaN and throw, src/Hmc.jl:435) */
 #define HMCG_ST_NONFINITE      4 /* non-finite observation: window skipped, outputs untouched */
 #define HMCG_ST_GAMMA_CAP      8 /* gamma rejection sampler hit its attempt cap */
-#define HMCG_ST_BAD_T         16 /* T[w] < 2 or T[w] > max_T: window skipped */
+#define HMCG_ST_BAD_T         16 /* T[w] < 2, T[w] > ldY or T[w] beyond what max_T was sized for: window skipped */
 
 /* flags */
 #define HMCG_FLAG_RESUME 1  /* chain state (extras.xstate) is loaded instead of the makeParams init; sweep numbering continues at sweep_base */

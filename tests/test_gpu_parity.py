@@ -196,6 +196,11 @@ def test_status_flags(hmclib, oracle):
     assert g["status"][1] == _lib.ST_NONFINITE
     assert g["status"][2] == _lib.ST_BAD_T
     assert (g["mu"][1:] == 0).all()                      # skipped windows leave their outputs untouched
+    Tbad = Tw.copy(); Tbad[0] = 301                       # longer than the panel row (ldY = 300)
+    assert _lib.estimate_batch_host(Y, Tbad, 3, 2, 5, (12,), None)["status"][0] == _lib.ST_BAD_T
+    xbad = np.full((3, 300), 7, dtype=np.int32)            # out-of-range initial states are clamped, not trusted
+    gb = _lib.estimate_batch_host(Y[:1], Tw[:1], 3, 0, 3, (12,), None, x_init=xbad[:1])
+    assert gb["status"][0] == 0 and np.isfinite(gb["mu"]).all()
     # Emission underflow (the reference would produce NaN and throw, src/Hmc.jl:435): teacher-force every
     # point, including one 1e6 outlier, into state 0 of a long window.  sd_0 ~ 1e6/sqrt(T) puts the outlier
     # 55 sd out, the empty states' prior draws put it ~1e6 sd out: all K pdfs underflow at that step.
