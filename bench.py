@@ -166,10 +166,10 @@ def main():
                        "K": K, "T": T, "windows_per_gpu": W_PER_GPU, "draws_per_window": DRAWS,
                        "parallelism": "windows sharded over %d GPU(s), no data-path collective; summary gather to rank 0" % world,
                        "threads_per_window": tm.threads_per_window, "steps_per_thread": tm.steps_per_thread,
-                       "lds_bytes_per_window": tm.lds_bytes, "windows_flagged": bad},
+                       "helper_waves": tm.helper_waves, "lds_bytes_per_window": tm.lds_bytes, "windows_flagged": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hmcg::gibbs_sweeps_kernel<3,%d,%d>" % (tm.steps_per_thread, tm.threads_per_window),
+                         "kernel": "hmcg::gibbs_sweeps_kernel<3,%d,%d,false,false,%d>" % (tm.steps_per_thread, tm.threads_per_window, tm.helper_waves),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": B * W_PER_GPU * DRAWS,
                          "note": "algorithmic bytes = 58160 B/draw (SURVEY 8d) x 256 windows x 1000 draws; the chain "
                                  "state is register/LDS-resident, so the physical limiter is fp64 VALU latency, not HBM"},

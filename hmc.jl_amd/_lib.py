@@ -47,7 +47,8 @@ class Extras(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int32), ("threads_per_window", C.c_int32),
-                ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32)]
+                ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32), ("helper_waves", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 _LIB = None
@@ -215,6 +216,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     out["threads_per_window"] = tm.threads_per_window
     out["steps_per_thread"] = tm.steps_per_thread
     out["lds_bytes"] = tm.lds_bytes
+    out["helper_waves"] = tm.helper_waves
     return out
 
 

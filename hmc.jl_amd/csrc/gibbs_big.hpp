@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         if (fc_e >= 0) sum_fc = p.sumacc[(size_t)w * NCK + NP + fc_e];
     }
     auto job_outputs = [&](int sw) {
-        const int d = kept_index(p, sw);
+        const int d = sw >= p.burnin_s ? sw - p.burnin_s : -1;       // one sample per launch on this path
         if (d < 0) return;
         const ThetaBufBig<K>& th = sh.th[sw & 1];
         const size_t nrun = (size_t)p.nd;

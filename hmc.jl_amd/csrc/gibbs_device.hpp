@@ -364,6 +364,14 @@ __device__ __forceinline__ double sqrt_fast(double x)
     return fma(fma(-g, g, x), 0.5 * r, g);
 }
 
+// 1/sqrt(x), x > 0 normal: hardware rsq + two Newton steps (<= 1 ulp)
+__device__ __forceinline__ double rsqrt_fast(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return fma(0.5 * r, fma(-x * r, r, 1.0), r);
+}
+
 // one level of the wave-wide inclusive matrix scan: Q <- (Q of the source lane) * Q
 template <int K, int CTRL, int RMASK>
 __device__ __forceinline__ void scan_level(double (&Q)[K * K])
@@ -463,7 +471,11 @@ __device__ __forceinline__ int map_apply(uint32_t m, int s) { return (int)((m >>
 // Julia round(x; digits=5) (basicsave, src/Hmc.jl:719)
 __device__ __forceinline__ double round5(double x)
 {
-    const double r = rint(x * 1e5) / 1e5;
+    // rint(x * 1e5) / 1e5 with the quotient from a reciprocal multiply and one residual correction (the
+    // result differs from the correctly rounded quotient by at most an ulp; the summary tolerance is 1e-9)
+    const double n = rint(x * 1e5);
+    const double q = n * 1e-5;
+    const double r = fma(fma(-q, 1e5, n), 1e-5, q);
     return isfinite(r) ? r : x;
 }
 
@@ -568,7 +580,7 @@ __device__ __forceinline__ double block_sum(double v, double* bred, int wave, in
 {
     v = wave_sum(v);
     __syncthreads();
-    if (lane == 0) bred[wave] = v;
+    if (lane == 0 && wave < NW) bred[wave] = v;      // helper waves (wave >= NW) only keep the barriers
     __syncthreads();
     double t = 0.0;
 #pragma unroll
@@ -580,7 +592,7 @@ __device__ __forceinline__ double block_minmax(double v, double* bred, int wave,
 {
     v = is_max ? wave_max(v) : wave_min(v);
     __syncthreads();
-    if (lane == 0) bred[wave] = v;
+    if (lane == 0 && wave < NW) bred[wave] = v;
     __syncthreads();
     double t = bred[0];
 #pragma unroll
@@ -629,9 +641,13 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 
 // ------------------------------------------------------------- kernel ----
 
-template <int K, int L, int NT, bool SIG = false, bool SMOOTH = false>
-__global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
+// NH > 0 adds NH "helper" waves (threads NT .. NT+64*NH-1) that own no time steps: they carry the per-draw
+// outputs, the forecasts, the next sweep's RNG preparation and a share of the Philox uniforms while wave 0
+// draws the parameters, sharing the SIMDs' issue slots with the primary waves (one helper per SIMD).
+template <int K, int L, int NT, bool SIG = false, bool SMOOTH = false, int NH = 0>
+__global__ __launch_bounds__(NT + 64 * NH) void gibbs_sweeps_kernel(const KernelParams p)
 {
+    static_assert(NH == 0 || (NH == 4 && NT == 256), "helper waves: 256 + 256 threads");
     static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter-draw roles fit one wave");
     static_assert(NT % 64 == 0 && NT >= 128, "at least two whole waves (wave 0 draws, the others work in its shadow)");
     constexpr int NW = NT / 64;
@@ -644,8 +660,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T[w];
-    const int t0 = tid * L;
+    const int t0 = tid * L;                                // helper threads: t0 >= NT*L >= T, so they own no step
     const int owner = (T - 1) / L, l_last = (T - 1) % L;   // thread and slot that hold the last time step
+    const bool helper = NH > 0 && __builtin_amdgcn_readfirstlane(wave) >= NW;   // wave-uniform
     int st = 0;
 
     if (T < 2 || T > NT * L || T > p.ldY) {   // uniform per block
@@ -715,13 +732,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
         const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
         // median by rank counting over the LDS-staged window
+        if (!helper) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) sh.ux[t0 + l] = y[l];
+            for (int l = 0; l < L; ++l) sh.ux[t0 + l] = y[l];
+        }
         __syncthreads();
         int rank[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) rank[l] = 0;
-        for (int j = 0; j < T; ++j) {
+        for (int j = 0; j < (helper ? 0 : T); ++j) {
             const double yj = sh.ux[j];
 #pragma unroll
             for (int l = 0; l < L; ++l) rank[l] += (yj < y[l] || (yj == y[l] && j < t0 + l)) ? 1 : 0;
@@ -761,14 +780,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
 
     // first state of the next thread's chunk (X at t0+L), and X[T-1]
     int xnext = 0;
-    sh.xfirst[tid] = x[0];
+    if (!helper) sh.xfirst[tid] = x[0];
     if (tid == 0) sh.xfirst[NT] = 0;
     if (tid == owner) {
 #pragma unroll
         for (int l = 0; l < L; ++l) if (l == l_last) sh.x_end = x[l];
     }
     __syncthreads();
-    xnext = sh.xfirst[tid + 1];
+    xnext = sh.xfirst[helper ? NT : tid + 1];
     int x_end = sh.x_end;
 
     Rng rng{p.seed_lo, p.seed_hi, p.window_ids ? p.window_ids[w] : p.window_base + (uint32_t)w, 0u};
@@ -843,9 +862,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
         }
     };
 
+    constexpr int FC_SPLIT_MAX = 26;      // beyond this, binary exponentiation (27 log2 h fma) beats 9 h/2
     double sum_acc = 0.0;                 // running sum behind `summary` (meaningful on the output lanes only)
-    constexpr int OUT_WAVE = 1;           // owns the 3K + K^2 parameter output lanes
-    constexpr int FC_WAVE = NW - 1;       // owns the 2H forecast lanes (== OUT_WAVE when NW == 2)
+    constexpr int OUT_WAVE = NH > 0 ? NW + 3 : 1;        // owns the 3K + K^2 parameter output lanes
+    constexpr int FC_WAVE = NH > 0 ? NW + 2 : NW - 1;    // owns the 2H forecast lanes (== OUT_WAVE when NW == 2)
+    constexpr int PREP_WAVE = NH > 0 ? NW + 1 : (NW - 1 >= 3 ? 2 : 1);   // prepares the next sweep's RNG parts
     const int NP = 3 * K + KK;
     int orole = -1;
     if (wave == OUT_WAVE && lane < NP) orole = lane;
@@ -875,21 +896,54 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     }
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
     auto job_outputs = [&](int sw) {
-        const int d = kept_index(p, sw);
+        // (without the signal path a launch is one sample: no division needed to find the kept-draw index)
+        const int d = SIG ? kept_index(p, sw) : (sw >= p.burnin_s ? sw - p.burnin_s : -1);
         if (d < 0 || orole < 0) return;
         const ThetaBuf<K>& th = sh.th[sw & 1];
         double val;
         if (o_which >= 4) {
             // forecast (src/Hmc.jl:658-667).  (pi' A^h) . mu is invariant under the label permutation, so the
             // unsorted parameters are used as they are.
-            double mu_u[K], pe_u[K], A_u[K][K];
+            double fv;
+            if (fc_h <= FC_SPLIT_MAX) {
+                // short horizons: the lane pair of a horizon (forecast, forecast error) meets in the middle --
+                // the even lane carries pi' A^(h/2) (as (A')^(h/2) pi), the odd lane A^(h - h/2) mu, one
+                // exchange and a dot product finish.  Half the dependent chain of the power iteration.
+                const int side = o_which - 4;
+                const int n_own = side ? fc_h - (fc_h >> 1) : (fc_h >> 1);
+                const double* Af = &th.A[0][0];
+                double M[K][K], v[K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                mu_u[i] = th.mu[i]; pe_u[i] = th.pi_end[i];
+                for (int i = 0; i < K; ++i) {
+                    v[i] = side ? th.mu[i] : th.pi_end[i];
 #pragma unroll
-                for (int j = 0; j < K; ++j) A_u[i][j] = th.A[i][j];
+                    for (int j = 0; j < K; ++j) M[i][j] = Af[side ? i * K + j : j * K + i];
+                }
+                for (int n = 0; n < n_own; ++n) {           // per-lane trip count (differs by at most one in a pair)
+                    double nv[K];
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        double acc = M[i][0] * v[0];
+#pragma unroll
+                        for (int j = 1; j < K; ++j) acc = fma(M[i][j], v[j], acc);
+                        nv[i] = acc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < K; ++i) v[i] = nv[i];
+                }
+                fv = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) fv = fma(v[i], __shfl_xor(v[i], 1, 64), fv);
+            } else {
+                double mu_u[K], pe_u[K], A_u[K][K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    mu_u[i] = th.mu[i]; pe_u[i] = th.pi_end[i];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) A_u[i][j] = th.A[i][j];
+                }
+                fv = forecast_value<K>(mu_u, A_u, pe_u, fc_h);
             }
-            const double fv = forecast_value<K>(mu_u, A_u, pe_u, fc_h);
             val = (o_which == 5) ? fv - fc_yr : fv;
         } else {
             double mu_u[K];
@@ -1062,10 +1116,33 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     if constexpr (SIG) {
         if (p.sweep_begin % p.per_sample != 0) regen_y(p.sweep_begin / p.per_sample, false);   // resumed inside a sample
     }
-    publish_stats();
+    if (!helper) publish_stats();
 
     // prologue: the first sweep's state-independent RNG parts
     if (p.sweep_begin < p.sweep_end && shadow_wave == 0) job_prep(p.sweep_begin);
+
+    // Philox blocks of the state-draw uniforms when helper waves exist: dealt in trips of 128 blocks (two per
+    // lane, ~1.1k cycles whatever the fill) to the waves with time to spare while wave 0 draws (~2.4k cycles):
+    // primary waves 1..3 carry nothing else (two trips each fit), helper 0 has no other job (it shares wave 0's
+    // SIMD, whose older wave keeps issue priority), then helper 3 (parameter outputs), the forecast and the
+    // RNG-preparation helpers; beyond that round-robin over the primaries.  Trip k covers blocks [128k, 128k+128).
+    uint32_t trips = 0;
+    if constexpr (NH > 0) {
+        const int ntrip = (((T + 1) >> 1) + 127) >> 7;
+        constexpr int trip_wave[10] = {1, 2, 3, NW, 1, 2, 3, NW + 3, NW + 2, NW + 1};
+        for (int k = 0; k < ntrip && k < 32; ++k) {
+            const int wv = k < 10 ? trip_wave[k] : 1 + (k - 10) % 3;
+            trips |= (wv == wave) ? (1u << k) : 0u;
+        }
+        trips = __builtin_amdgcn_readfirstlane(trips);
+    }
+    auto job_uniform_trips = [&](int sw) {
+        const int nblk = (T + 1) >> 1;
+        for (uint32_t m = trips; m != 0; m &= m - 1) {
+            const int k = __builtin_ctz(m);
+            job_uniforms(sw, k << 7, min((k << 7) + 128, nblk));
+        }
+    };
 
     double pf[L][K];     // unsorted filtered probabilities of this thread's steps
     double sm_acc[SMOOTH ? L : 1][K];   // running sums of the smoothed probabilities of this thread's steps
@@ -1082,7 +1159,29 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
+    if constexpr (NH > 0) {
+        if (helper) {
+            // ---- helper waves: the draw-phase jobs, then only the sweep's barriers ----
+            for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
+                __syncthreads();                                             // Ba
+                STAMP(0);
+                if (sweep > p.sweep_begin) job_outputs(sweep - 1);
+                STAMP(14);
+                if (wave == PREP_WAVE && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
+                STAMP(15);
+                job_uniform_trips(sweep);
+                STAMP(1);
+                __syncthreads();                                             // Bb
+                STAMP(2);
+                __syncthreads();                                             // Bc
+                __syncthreads();                                             // Bd
+                __syncthreads();                                             // Be
+                STAMP(11);
+            }
+        }
+    }
+
+    for (int sweep = helper ? p.sweep_end : p.sweep_begin; sweep < p.sweep_end; ++sweep) {
         rng.sweep = (uint32_t)sweep;
         const int par = sweep & 1;
         ThetaBuf<K>& th = sh.th[par];
@@ -1097,7 +1196,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             const RngBuf<K>& rb = sh.rb[par];
             const int role = lane;
             const bool is_sig = role < K, is_g = role < NG;
-            double shape = 1.0, bpar = 1.0, Neff = 0.0, Ssum = 0.0;
+            double shape = 1.0, bpar = 1.0, Neff = 0.0, Ssum = 0.0, rnn = 0.0;
             // transition count C_e of this lane's A role (e = role - K), summed over the waves' packed words
             int cT = 0;
             {
@@ -1128,7 +1227,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                         Ssum = piv * Neff + d1;                                      // sum of y in the state
                         const double dm = ybar - xi;
                         shape = p.alpha + 0.5 * Neff;                                // :313
-                        bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
+                        rnn = rcp_fast(Neff + p.nu);
+                        bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu * rnn * (dm * dm);   // :314
                     } else {
                         // observation set and signal set (src/Hmc.jl:254-314)
                         int Mi = 0;
@@ -1150,7 +1250,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                         Ssum = S + Sm;                                                              // :331 (Sm unscaled: quirk 4)
                         const double dm = totalbar - xi;
                         shape = p.alpha + 0.5 * dNi + 0.5 * dMi;                                    // :313
-                        bpar = beta + 0.5 * S2 + (0.5 * kfac) * Sm2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);   // :314
+                        rnn = rcp_fast(Neff + p.nu);
+                        bpar = beta + 0.5 * S2 + (0.5 * kfac) * Sm2 + 0.5 * Neff * p.nu * rnn * (dm * dm);   // :314
                     }
                 } else {
                     shape = (double)(c + 1);                                     // :362-365
@@ -1168,7 +1269,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 } else {
                     const double a = shape < 1.0 ? shape + 1.0 : shape;
                     const double dd = a - 1.0 / 3.0;
-                    const double cc = rcp_fast(3.0 * sqrt_fast(dd));
+                    const double cc = rsqrt_fast(dd) * (1.0 / 3.0);               // 1 / (3 sqrt(d))
                     val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0]);
                     if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1]);
                     if (val < 0.0) {
@@ -1197,12 +1298,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             for (int j = 0; j < K; ++j) gs += __shfl(val, gbase + j, 64);
             if (is_sig) {
                 const double sig2 = bpar * rcp_fast(val);                        // :320 InverseGamma(a,b) = b / Gamma(a,1)
-                const double rnn = rcp_fast(Neff + p.nu);
                 const double m = (Ssum + p.nu * xi) * rnn;                       // :331
-                const double sd = sqrt_fast(sig2);                               // :381
-                const double sdev = sd * sqrt_fast(rnn);                         // :332 sqrt(sig2/(Neff+nu))
+                const double sdev = sqrt_fast(sig2 * rnn);                       // :332 sqrt(sig2/(Neff+nu))
                 const double mu = m + sdev * rb.z[role];                         // :334
-                const double isd = rcp_fast(sd);
+                const double isd = rsqrt_fast(sig2);                             // 1/sd (:381)
                 th.mu[role] = mu; th.sig2[role] = sig2;
                 th.isd[role] = isd * 0.70710678118654752440; th.coef[role] = INVSQRT2PI * isd;
                 th.rho[role] = rb.rho[role];                                     // :355
@@ -1218,7 +1317,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
             const int nblk = (T + 1) >> 1;
             if (sweep > p.sweep_begin) job_outputs(sweep - 1);
             STAMP(14);
-            if (NSH >= 3) {
+            if constexpr (NH > 0) {
+                job_uniform_trips(sweep);
+            } else if (NSH >= 3) {
                 // fixed jobs: wave 1 parameter outputs (~1.0k cycles), wave 2 RNG preparation (~1.5k), last
                 // wave forecasts (~2.1k); the Philox blocks (~0.5k cycles per lane-block) fill them up to an
                 // even finish: shares in 1/16ths = 8 (wave 1), 5 (wave 2), 3 (last), any further waves take
@@ -1464,7 +1565,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
                 b[r] = acc;
             }
             rescale_pow2<K>(b);
-            const bool kept = kept_index(p, sweep) >= 0;
+            const bool kept = sweep >= p.burnin_s;           // SMOOTH excludes the signal path: one sample
 #pragma unroll
             for (int l = L - 1; l >= 0; --l) {
                 if (t0 + l < T) {
@@ -1581,7 +1682,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel(const KernelParams p)
     }
 #ifdef HMCG_STAMPS
     if (lane == 0 && p.dbg)
-        for (int i = 0; i < HMCG_NSTAMP; ++i) p.dbg[((size_t)w * NW + wave) * HMCG_NSTAMP + i] = stamp_acc[i];
+        for (int i = 0; i < HMCG_NSTAMP; ++i) p.dbg[((size_t)w * (NW + NH) + wave) * HMCG_NSTAMP + i] = stamp_acc[i];
 #endif
 
     // ---- epilogue: the last sweep's outputs, checkpoint / debug outputs ----

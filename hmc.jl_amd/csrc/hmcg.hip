@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -40,6 +41,7 @@ struct Context {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cu_count = 0;
 };
 Context g_ctx;
 
@@ -61,6 +63,7 @@ int ensure_context(int device)
         HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&g_ctx.ev0));
         HIP_TRY(hipEventCreate(&g_ctx.ev1));
+        HIP_TRY(hipDeviceGetAttribute(&g_ctx.cu_count, hipDeviceAttributeMultiprocessorCount, device));
         g_ctx.device = device;
     }
     return 0;
@@ -72,23 +75,24 @@ struct Variant {
     int K, L, NT;
     KernelFn fn;
     bool sig, smooth;
+    int NH = 0;            // helper waves on top of the NT window threads (block = NT + 64*NH threads)
 };
 
-#define HMCG_VARIANT(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, false, false>, false, false }
-#define HMCG_VARIANT_SIG(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, true, false>, true, false }
-#define HMCG_VARIANT_SMOOTH(K_, L_, NT_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, false, true>, false, true }
+#define HMCG_V(K_, L_, NT_, SIG_, SM_, NH_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, SIG_, SM_, NH_>, SIG_, SM_, NH_ }
+// every 256-thread variant exists plain and with four helper waves (HMCG_V2)
+#define HMCG_V2(K_, L_, SIG_, SM_) HMCG_V(K_, L_, 256, SIG_, SM_, 0), HMCG_V(K_, L_, 256, SIG_, SM_, 4)
 const Variant g_variants[] = {
-    HMCG_VARIANT(2, 1, 256), HMCG_VARIANT(2, 2, 256), HMCG_VARIANT(2, 4, 256), HMCG_VARIANT(2, 8, 256),
-    HMCG_VARIANT(3, 1, 256), HMCG_VARIANT(3, 2, 256), HMCG_VARIANT(3, 4, 256), HMCG_VARIANT(3, 8, 256),
-    HMCG_VARIANT(3, 16, 256),
-    HMCG_VARIANT(3, 2, 512), HMCG_VARIANT(3, 8, 128),
-    HMCG_VARIANT(4, 1, 256), HMCG_VARIANT(4, 2, 256), HMCG_VARIANT(4, 4, 256), HMCG_VARIANT(4, 8, 256),
+    HMCG_V2(2, 1, false, false), HMCG_V2(2, 2, false, false), HMCG_V2(2, 4, false, false), HMCG_V2(2, 8, false, false),
+    HMCG_V2(3, 1, false, false), HMCG_V2(3, 2, false, false), HMCG_V2(3, 4, false, false), HMCG_V2(3, 8, false, false),
+    HMCG_V2(3, 16, false, false),
+    HMCG_V(3, 2, 512, false, false, 0), HMCG_V(3, 8, 128, false, false, 0),
+    HMCG_V2(4, 1, false, false), HMCG_V2(4, 2, false, false), HMCG_V2(4, 4, false, false), HMCG_V2(4, 8, false, false),
     // signal Monte-Carlo path (estimatesignals!): two-population statistics, per-step emission scale
-    HMCG_VARIANT_SIG(2, 1, 256), HMCG_VARIANT_SIG(2, 2, 256), HMCG_VARIANT_SIG(2, 4, 256),
-    HMCG_VARIANT_SIG(3, 1, 256), HMCG_VARIANT_SIG(3, 2, 256), HMCG_VARIANT_SIG(3, 4, 256), HMCG_VARIANT_SIG(3, 8, 256),
+    HMCG_V2(2, 1, true, false), HMCG_V2(2, 2, true, false), HMCG_V2(2, 4, true, false),
+    HMCG_V2(3, 1, true, false), HMCG_V2(3, 2, true, false), HMCG_V2(3, 4, true, false), HMCG_V2(3, 8, true, false),
     // with the smoothed-probability output (full backward pass every sweep)
-    HMCG_VARIANT_SMOOTH(2, 1, 256), HMCG_VARIANT_SMOOTH(2, 2, 256), HMCG_VARIANT_SMOOTH(2, 4, 256),
-    HMCG_VARIANT_SMOOTH(3, 1, 256), HMCG_VARIANT_SMOOTH(3, 2, 256), HMCG_VARIANT_SMOOTH(3, 4, 256), HMCG_VARIANT_SMOOTH(3, 8, 256),
+    HMCG_V2(2, 1, false, true), HMCG_V2(2, 2, false, true), HMCG_V2(2, 4, false, true),
+    HMCG_V2(3, 1, false, true), HMCG_V2(3, 2, false, true), HMCG_V2(3, 4, false, true), HMCG_V2(3, 8, false, true),
 };
 
 using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
@@ -104,13 +108,14 @@ const BigVariant g_big_variants[] = {
 };
 constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
-const Variant* pick_variant(int K, int maxT, int nt_req, bool sig, bool smooth)
+const Variant* pick_variant(int K, int maxT, int nt_req, bool sig, bool smooth, bool helpers)
 {
     const int nt = nt_req > 0 ? nt_req : 256;
     const Variant* best = nullptr;
     for (const Variant& v : g_variants) {
         if (v.K != K || v.NT != nt || v.L * v.NT < maxT || v.sig != sig || v.smooth != smooth) continue;
-        if (!best || v.L < best->L) best = &v;
+        if (v.NH > 0 && !helpers) continue;
+        if (!best || v.L < best->L || (v.L == best->L && v.NH > best->NH)) best = &v;
     }
     return best;
 }
@@ -155,7 +160,12 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     size_t dyn = 0;
     const bool use_smooth = ex && ex->pi_smooth_mean != nullptr;
     if (use_smooth && use_sig) { set_err("pi_smooth_mean is not available on the signal path"); return HMCG_E_UNSUPPORTED; }
-    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth);
+    // Helper waves pay off while every window has a CU to itself; with more windows than CUs the plain
+    // variant lets two windows share a CU instead (a helped block takes the whole register file).
+    // HMCG_HELPERS=0/1 overrides the rule (diagnostics).
+    const char* henv = getenv("HMCG_HELPERS");
+    const bool helpers = henv ? atoi(henv) != 0 : cfg->W <= g_ctx.cu_count;
+    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, helpers);
     if (!v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
         for (const BigVariant& b : g_big_variants) if (b.K == cfg->K) bv = &b;
         if (bv) {
@@ -199,14 +209,14 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     if (bv) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bv->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     if (timing) HIP_TRY(hipEventRecord(g_ctx.ev0, stream));
 #ifdef HMCG_STAMPS
-    const int nwv = vNT / 64;
+    const int nwv = vNT / 64 + (v ? v->NH : 0);
     const size_t ndbg = (size_t)cfg->W * nwv * HMCG_NSTAMP;
     unsigned long long* ddbg = nullptr;
     HIP_TRY(hipMalloc((void**)&ddbg, ndbg * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(ddbg, 0, ndbg * sizeof(unsigned long long), stream));
     p.dbg = ddbg;
 #endif
-    if (v) hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)v->NT), 0, stream, p);
+    if (v) hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)(v->NT + 64 * v->NH)), 0, stream, p);
     else hipLaunchKernelGGL(bv->fn, dim3((unsigned)cfg->W), dim3((unsigned)bv->NT), dyn, stream, p, bigL);
     HIP_TRY(hipGetLastError());
 #ifdef HMCG_STAMPS
@@ -248,6 +258,8 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
         timing->launches = 1;
         timing->threads_per_window = vNT;
         timing->steps_per_thread = vL;
+        timing->helper_waves = v ? v->NH : 0;
+        timing->reserved = 0;
         hipFuncAttributes fa{};
         const void* fptr = v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn);
         if (hipFuncGetAttributes(&fa, fptr) == hipSuccess)

@@ -136,6 +136,8 @@ typedef struct hmcg_timing {
     int32_t threads_per_window;
     int32_t steps_per_thread;
     int32_t lds_bytes;
+    int32_t helper_waves;    /* extra 64-thread waves per window that carry the draw-phase side jobs (0 or 4) */
+    int32_t reserved;
 } hmcg_timing;
 
 int hmcg_version(void);

@@ -256,6 +256,34 @@ def test_threads_per_window_variants_agree(hmclib, oracle):
         check_against_oracle(oracle, Y, Tw, 3, 2, 20, (12,), fut[:, 11:12], threads_per_window=tpw)
 
 
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_helper_wave_variants_are_bit_identical(hmclib, monkeypatch, K):
+    """With at most one window per CU the library adds four helper waves per window (draw-phase jobs off the
+    window's own threads); beyond that it runs the plain kernels.  Both do the same arithmetic on the same
+    counter-based random numbers, so every output must agree bit for bit -- on every steps-per-thread
+    variant, on the signal path and with the smoothed-probability output."""
+    lens = [5, 200, 256, 500, 1000, 2047]
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
+    for sub in ([0, 1, 2], [3], [4], [5]):
+        idx = np.array(sub)
+        ld = int(Tw[idx].max())
+        args = (np.ascontiguousarray(Y[idx, :ld]), Tw[idx], K, 3, 12, (3, 12, 40),
+                np.column_stack([fut[idx, 2], fut[idx, 11], np.zeros(len(idx))]))      # h=40 takes the long-horizon branch
+        extra = [dict()]
+        if K <= 3 and ld <= 1024:
+            sig = np.stack([np.maximum(Tw[idx] - 12, 0), Tw[idx]], axis=1).astype(np.int32)
+            extra += [dict(sig_range=sig, kappa=1.0, n_samples=2, sigma_signal=np.full(len(idx), 0.3)), dict(want_smooth=True)]
+        for kw in extra:
+            monkeypatch.setenv("HMCG_HELPERS", "1")
+            a = _lib.estimate_batch_host(*args, want_state=True, window_ids=idx, **kw)
+            monkeypatch.setenv("HMCG_HELPERS", "0")
+            b = _lib.estimate_batch_host(*args, want_state=True, window_ids=idx, **kw)
+            for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "x_final", "pif_final", "status"):
+                assert np.array_equal(a[k], b[k], equal_nan=True), (K, sub, sorted(kw), k)
+            if "want_smooth" in kw:
+                assert np.array_equal(a["pi_smooth_mean"], b["pi_smooth_mean"])
+
+
 def test_full_size_cfg2_properties_and_subset_parity(hmclib, oracle):
     """BASELINE configs[1] at full size (256 windows, T=1000, 1000 draws): size-independent
     properties on everything, oracle parity on a subset of windows at full length."""
