@@ -644,8 +644,12 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 // NH > 0 adds NH "helper" waves (threads NT .. NT+64*NH-1) that own no time steps: they carry the per-draw
 // outputs, the forecasts, the next sweep's RNG preparation and a share of the Philox uniforms while wave 0
 // draws the parameters, sharing the SIMDs' issue slots with the primary waves (one helper per SIMD).
-template <int K, int L, int NT, bool SIG = false, bool SMOOTH = false, int NH = 0>
-__global__ __launch_bounds__(NT + 64 * NH) void gibbs_sweeps_kernel(const KernelParams p)
+// OCC = 2 caps the registers so that two blocks of a plain 256-thread variant fit one CU (for batches with more
+// windows than CUs); OCC = 1 gives a lone block the whole register file.  (A helped block is eight waves, two per
+// SIMD, by itself.)
+template <int K, int L, int NT, bool SIG = false, bool SMOOTH = false, int NH = 0, int OCC = 1>
+__global__ __launch_bounds__(NT + 64 * NH) __attribute__((amdgpu_waves_per_eu(OCC)))
+void gibbs_sweeps_kernel(const KernelParams p)
 {
     static_assert(NH == 0 || (NH == 4 && NT == 256), "helper waves: 256 + 256 threads");
     static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter-draw roles fit one wave");

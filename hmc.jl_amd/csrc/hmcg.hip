@@ -75,24 +75,39 @@ struct Variant {
     int K, L, NT;
     KernelFn fn;
     bool sig, smooth;
-    int NH = 0;            // helper waves on top of the NT window threads (block = NT + 64*NH threads)
+    int NH;                // helper waves on top of the NT window threads (block = NT + 64*NH threads)
+    int occ;               // 2: registers capped so that two plain blocks share a CU
+    int pref_small;        // flavour to run when every window has a CU to itself (W <= CU count)
+    int pref_big;          // flavour for larger batches
 };
+// flavours: P1 = plain, whole register file; P2 = plain, two blocks per CU; H = four helper waves
+enum { P1 = 0, P2 = 1, H = 2 };
+int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
 
-#define HMCG_V(K_, L_, NT_, SIG_, SM_, NH_) { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, SIG_, SM_, NH_>, SIG_, SM_, NH_ }
-// every 256-thread variant exists plain and with four helper waves (HMCG_V2)
-#define HMCG_V2(K_, L_, SIG_, SM_) HMCG_V(K_, L_, 256, SIG_, SM_, 0), HMCG_V(K_, L_, 256, SIG_, SM_, 4)
+#define HMCG_V(K_, L_, NT_, SIG_, SM_, NH_, OCC_, PS_, PB_) \
+    { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, SIG_, SM_, NH_, OCC_>, SIG_, SM_, NH_, OCC_, PS_, PB_ }
+// every 256-thread variant in the three flavours, with the one to prefer for small and for large batches
+// (measured: tools/variant_sweep.py, profiles/r01/variant_sweep.txt -- helper waves win while they fit the
+// 256-register cap without spilling, capped plain blocks win once two windows can share a CU)
+#define HMCG_V3(K_, L_, SIG_, SM_, PS_, PB_)                                                   \
+    HMCG_V(K_, L_, 256, SIG_, SM_, 0, 1, PS_, PB_), HMCG_V(K_, L_, 256, SIG_, SM_, 0, 2, PS_, PB_), \
+    HMCG_V(K_, L_, 256, SIG_, SM_, 4, 2, PS_, PB_)
 const Variant g_variants[] = {
-    HMCG_V2(2, 1, false, false), HMCG_V2(2, 2, false, false), HMCG_V2(2, 4, false, false), HMCG_V2(2, 8, false, false),
-    HMCG_V2(3, 1, false, false), HMCG_V2(3, 2, false, false), HMCG_V2(3, 4, false, false), HMCG_V2(3, 8, false, false),
-    HMCG_V2(3, 16, false, false),
-    HMCG_V(3, 2, 512, false, false, 0), HMCG_V(3, 8, 128, false, false, 0),
-    HMCG_V2(4, 1, false, false), HMCG_V2(4, 2, false, false), HMCG_V2(4, 4, false, false), HMCG_V2(4, 8, false, false),
+    HMCG_V3(2, 1, false, false, H, P2), HMCG_V3(2, 2, false, false, H, P2), HMCG_V3(2, 4, false, false, H, P2),
+    HMCG_V3(2, 8, false, false, H, P2),
+    HMCG_V3(3, 1, false, false, P1, P2), HMCG_V3(3, 2, false, false, H, P2), HMCG_V3(3, 4, false, false, H, P2),
+    HMCG_V3(3, 8, false, false, H, P2), HMCG_V3(3, 16, false, false, P1, P1),
+    HMCG_V(3, 2, 512, false, false, 0, 1, P1, P1), HMCG_V(3, 8, 128, false, false, 0, 1, P1, P1),
+    HMCG_V3(4, 1, false, false, P1, P2), HMCG_V3(4, 2, false, false, H, P2), HMCG_V3(4, 4, false, false, H, P2),
+    HMCG_V3(4, 8, false, false, H, P2),
     // signal Monte-Carlo path (estimatesignals!): two-population statistics, per-step emission scale
-    HMCG_V2(2, 1, true, false), HMCG_V2(2, 2, true, false), HMCG_V2(2, 4, true, false),
-    HMCG_V2(3, 1, true, false), HMCG_V2(3, 2, true, false), HMCG_V2(3, 4, true, false), HMCG_V2(3, 8, true, false),
+    HMCG_V3(2, 1, true, false, H, P2), HMCG_V3(2, 2, true, false, H, P2), HMCG_V3(2, 4, true, false, H, P2),
+    HMCG_V3(3, 1, true, false, P1, P2), HMCG_V3(3, 2, true, false, P1, P2), HMCG_V3(3, 4, true, false, H, P2),
+    HMCG_V3(3, 8, true, false, H, P2),
     // with the smoothed-probability output (full backward pass every sweep)
-    HMCG_V2(2, 1, false, true), HMCG_V2(2, 2, false, true), HMCG_V2(2, 4, false, true),
-    HMCG_V2(3, 1, false, true), HMCG_V2(3, 2, false, true), HMCG_V2(3, 4, false, true), HMCG_V2(3, 8, false, true),
+    HMCG_V3(2, 1, false, true, H, P2), HMCG_V3(2, 2, false, true, H, P2), HMCG_V3(2, 4, false, true, H, P2),
+    HMCG_V3(3, 1, false, true, P1, P2), HMCG_V3(3, 2, false, true, H, P2), HMCG_V3(3, 4, false, true, H, P2),
+    HMCG_V3(3, 8, false, true, P1, P2),
 };
 
 using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
@@ -108,14 +123,19 @@ const BigVariant g_big_variants[] = {
 };
 constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
-const Variant* pick_variant(int K, int maxT, int nt_req, bool sig, bool smooth, bool helpers)
+// The variant for (K, longest window, threads per window, path): the fewest steps per thread that cover the
+// window, then the flavour -- `force` (>= 0, diagnostics) or the table's preference for the batch size.
+const Variant* pick_variant(int K, int maxT, int nt_req, bool sig, bool smooth, bool small_batch, int force)
 {
     const int nt = nt_req > 0 ? nt_req : 256;
     const Variant* best = nullptr;
     for (const Variant& v : g_variants) {
         if (v.K != K || v.NT != nt || v.L * v.NT < maxT || v.sig != sig || v.smooth != smooth) continue;
-        if (v.NH > 0 && !helpers) continue;
-        if (!best || v.L < best->L || (v.L == best->L && v.NH > best->NH)) best = &v;
+        const int want = force >= 0 ? force : (small_batch ? v.pref_small : v.pref_big);
+        const bool better = !best || v.L < best->L ||
+                            (v.L == best->L && flavour_of(v) == want) ||
+                            (v.L == best->L && flavour_of(*best) != want && flavour_of(v) == P1);
+        if (better) best = &v;
     }
     return best;
 }
@@ -160,12 +180,14 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     size_t dyn = 0;
     const bool use_smooth = ex && ex->pi_smooth_mean != nullptr;
     if (use_smooth && use_sig) { set_err("pi_smooth_mean is not available on the signal path"); return HMCG_E_UNSUPPORTED; }
-    // Helper waves pay off while every window has a CU to itself; with more windows than CUs the plain
-    // variant lets two windows share a CU instead (a helped block takes the whole register file).
-    // HMCG_HELPERS=0/1 overrides the rule (diagnostics).
-    const char* henv = getenv("HMCG_HELPERS");
-    const bool helpers = henv ? atoi(henv) != 0 : cfg->W <= g_ctx.cu_count;
-    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, helpers);
+    // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
+    // plain variant lets two windows share a CU instead (a helped block takes the whole register file).
+    // HMCG_FLAVOUR=p1|p2|h and HMCG_HELPERS=0|1 override the table (diagnostics, tools/variant_sweep.py).
+    const bool small_batch = cfg->W <= g_ctx.cu_count;
+    int force = -1;
+    if (const char* henv = getenv("HMCG_HELPERS")) force = atoi(henv) != 0 ? H : (small_batch ? P1 : P2);
+    if (const char* fenv = getenv("HMCG_FLAVOUR")) force = !strcmp(fenv, "h") ? H : (!strcmp(fenv, "p2") ? P2 : P1);
+    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
     if (!v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
         for (const BigVariant& b : g_big_variants) if (b.K == cfg->K) bv = &b;
         if (bv) {

@@ -257,11 +257,12 @@ def test_threads_per_window_variants_agree(hmclib, oracle):
 
 
 @pytest.mark.parametrize("K", [2, 3, 4])
-def test_helper_wave_variants_are_bit_identical(hmclib, monkeypatch, K):
-    """With at most one window per CU the library adds four helper waves per window (draw-phase jobs off the
-    window's own threads); beyond that it runs the plain kernels.  Both do the same arithmetic on the same
-    counter-based random numbers, so every output must agree bit for bit -- on every steps-per-thread
-    variant, on the signal path and with the smoothed-probability output."""
+def test_kernel_flavours_are_bit_identical(hmclib, monkeypatch, K):
+    """Each kernel variant exists in three flavours -- plain, plain with registers capped so that two windows
+    share a CU, and with four helper waves per window (draw-phase jobs off the window's own threads) -- and
+    the library picks by batch size.  All do the same arithmetic on the same counter-based random numbers,
+    so every output must agree bit for bit: on every steps-per-thread variant, on the signal path and with
+    the smoothed-probability output."""
     lens = [5, 200, 256, 500, 1000, 2047]
     Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
     for sub in ([0, 1, 2], [3], [4], [5]):
@@ -274,14 +275,31 @@ def test_helper_wave_variants_are_bit_identical(hmclib, monkeypatch, K):
             sig = np.stack([np.maximum(Tw[idx] - 12, 0), Tw[idx]], axis=1).astype(np.int32)
             extra += [dict(sig_range=sig, kappa=1.0, n_samples=2, sigma_signal=np.full(len(idx), 0.3)), dict(want_smooth=True)]
         for kw in extra:
-            monkeypatch.setenv("HMCG_HELPERS", "1")
-            a = _lib.estimate_batch_host(*args, want_state=True, window_ids=idx, **kw)
-            monkeypatch.setenv("HMCG_HELPERS", "0")
-            b = _lib.estimate_batch_host(*args, want_state=True, window_ids=idx, **kw)
-            for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "x_final", "pif_final", "status"):
-                assert np.array_equal(a[k], b[k], equal_nan=True), (K, sub, sorted(kw), k)
-            if "want_smooth" in kw:
-                assert np.array_equal(a["pi_smooth_mean"], b["pi_smooth_mean"])
+            res = {}
+            for fl in ("p1", "p2", "h"):       # plain / plain capped for two blocks per CU / helper waves
+                monkeypatch.setenv("HMCG_FLAVOUR", fl)
+                res[fl] = _lib.estimate_batch_host(*args, want_state=True, window_ids=idx, **kw)
+            assert res["h"]["helper_waves"] == 4 and res["p1"]["helper_waves"] == 0
+            for fl in ("p2", "h"):
+                a, b = res["p1"], res[fl]
+                for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "x_final", "pif_final", "status"):
+                    assert np.array_equal(a[k], b[k], equal_nan=True), (K, sub, sorted(kw), fl, k)
+                if "want_smooth" in kw:
+                    assert np.array_equal(a["pi_smooth_mean"], b["pi_smooth_mean"])
+
+
+def test_batch_larger_than_the_gpu_matches_small_batches(hmclib):
+    """More windows than CUs switches the library to the two-windows-per-CU kernels; rows must not depend on
+    the batch they were computed in."""
+    W = 600
+    Y, Tw, fut = synth.generate_panel(W, 300, 3)
+    big = _lib.estimate_batch_host(Y, Tw, 3, 2, 6, (12,), fut[:, 11:12], want_state=True)
+    assert big["helper_waves"] == 0
+    ids = np.array([0, 299, 300, 599])
+    small = _lib.estimate_batch_host(Y[ids], Tw[ids], 3, 2, 6, (12,), fut[ids, 11:12], want_state=True, window_ids=ids)
+    assert small["helper_waves"] == 4
+    for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "x_final", "pif_final", "status"):
+        assert np.array_equal(big[k][ids], small[k]), k
 
 
 def test_full_size_cfg2_properties_and_subset_parity(hmclib, oracle):
