@@ -20,6 +20,7 @@ FLAG_RESUME = 1
 
 ST_BAD_INVGAMMA, ST_EMIS_UNDERFLOW, ST_NONFINITE, ST_GAMMA_CAP, ST_BAD_T = 1, 2, 4, 8, 16
 
+HMCG_MAXTAIL = 32
 EXPORTS = ("hmcg_version", "hmcg_device_count", "hmcg_last_error", "hmcg_shutdown",
            "hmcg_estimate_batch", "hmcg_estimate_batch_device")
 
@@ -34,7 +35,7 @@ class Config(C.Structure):
                 ("horizons", C.c_int32 * HMCG_MAXH), ("seed", C.c_uint64), ("window_base", C.c_uint32),
                 ("device", C.c_int32), ("flags", C.c_int32), ("threads_per_window", C.c_int32),
                 ("sweep_base", C.c_int32), ("sweep_count", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double),
-                ("kappa", C.c_double), ("n_samples", C.c_int32), ("reserved1", C.c_int32)]
+                ("kappa", C.c_double), ("n_samples", C.c_int32), ("blend_mask", C.c_int32)]
 
 
 class Extras(C.Structure):
@@ -42,7 +43,7 @@ class Extras(C.Structure):
                 ("x_final", C.c_void_p), ("pif_final", C.c_void_p), ("xstate", C.c_void_p), ("sumacc", C.c_void_p), ("window_ids", C.c_void_p),
                 ("sig_range", C.c_void_p), ("save_range", C.c_void_p), ("sigma_signal", C.c_void_p),
                 ("sigvals", C.c_void_p), ("nsave_ld", C.c_int32), ("reserved2", C.c_int32),
-                ("pi_smooth_mean", C.c_void_p)]
+                ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p)]
 
 
 class Timing(C.Structure):
@@ -118,7 +119,8 @@ def _check(rc):
 
 
 def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base=0, device=0, flags=0,
-                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0, sweep_count=0, kappa=0.0, n_samples=0):
+                threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0, sweep_count=0, kappa=0.0, n_samples=0,
+                blend_mask=0):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.W, cfg.K, cfg.ldY, cfg.max_T = int(W), int(K), int(ldY), int(max_T)
@@ -133,6 +135,7 @@ def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base
     cfg.threads_per_window, cfg.sweep_base = int(threads_per_window), int(sweep_base)
     cfg.sweep_count = int(sweep_count)
     cfg.kappa, cfg.n_samples = float(kappa), int(n_samples)
+    cfg.blend_mask = int(blend_mask)
     cfg.alpha, cfg.nu = float(alpha), float(nu)
     return cfg
 
@@ -144,7 +147,8 @@ def _np_ptr(a):
 def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, window_base=0, device=0,
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
-                        sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False):
+                        sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
+                        end_pos=None, blend_mask=0):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,)."""
@@ -185,6 +189,9 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         if sigma_signal is not None:
             ssg = np.ascontiguousarray(sigma_signal, dtype=np.float64).reshape(W)
             ex.sigma_signal = ssg.ctypes.data
+        if end_pos is not None:                    # signals past the end date (sigLen > 0)
+            epos = np.ascontiguousarray(end_pos, dtype=np.int32).reshape(W)
+            ex.end_pos = epos.ctypes.data
     if want_smooth:
         out["pi_smooth_mean"] = np.zeros((W, ldY, K))
         ex.pi_smooth_mean = out["pi_smooth_mean"].ctypes.data
@@ -205,7 +212,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         ex.xstate = out["xstate"].ctypes.data
         ex.sumacc = out["sumacc"].ctypes.data
     cfg = make_config(W, K, ldY, min(int(T.max()), ldY), burnin, nrun, horizons, seed, window_base, device, flags,
-                      threads_per_window, sweep_base, alpha, nu, sweep_count, kappa, n_samples)
+                      threads_per_window, sweep_base, alpha, nu, sweep_count, kappa, n_samples, blend_mask)
     tm = Timing()
     rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
                                _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),

@@ -68,6 +68,10 @@ struct KernelParams {
     const double* sigma_signal;     // [W] sd of the noise added to the signal positions of each sample
     double* sigvals;                // [W][n_samples][nsave_ld]
     int32_t nsave_ld;
+    // signals past the end date (sigLen = T-1-end_pos > 0, src/Hmc.jl:888): pi_end reports the SMOOTHED
+    // probabilities at end_pos (:900); horizons in blend_mask go through forecastsignal (:908-909)
+    const int32_t* end_pos;         // [W] 0-based, T-1-HMCG_MAXTAIL <= end_pos <= T-1; null = T-1
+    int32_t blend_mask;
     // smoothed probabilities (backwardupdate_P!, src/Hmc.jl:442-457): running sum over the kept draws of
     // P(X_t | Y_1:T, theta) in SORTED labels, [W][ldY][K]; divided by nd at the final launch
     double* pi_smooth_mean;
@@ -573,6 +577,11 @@ struct SweepShared {
     double med[2];
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
     double exptab[32];            // 2^(j/32), j = 0..31
+    // signal path with signals past the end date: the (scaled) emission values of the last `tail` steps, the
+    // filtered probabilities at end_pos, and the current noise sample's last observation (by sample parity)
+    double ftail[SIG ? HMCG_MAXTAIL : 1][K];
+    double pf_rep[K];
+    double y_last[2];
 };
 
 template <int NW>
@@ -701,7 +710,15 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int l = 0; l < L; ++l) yreal[l] = y[l];
     }
-    (void)kfac; (void)yreal; (void)sb; (void)se;
+    int tail = 0;                         // steps after the position whose smoothed probabilities are reported
+    if constexpr (SIG) {
+        if (p.end_pos) tail = (T - 1) - p.end_pos[w];
+        if (tail < 0 || tail > HMCG_MAXTAIL || tail > T - 1) {      // uniform per block
+            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+            return;
+        }
+    }
+    (void)kfac; (void)yreal; (void)sb; (void)se; (void)tail;
 
     // ---- HyperParams(Y,D): xi = mean(Y)  (src/Hmc.jl:136); always the mean of the REAL window ----
     double part = 0.0;
@@ -879,6 +896,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     // per-lane constants of the output role (decoded once per launch)
     double* out_base = nullptr;           // element (d=0) of this lane's output column
     int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0;
+    bool fc_blend = false;                // signal path: this horizon is a forecastsignal blend
     double fc_yr = 0.0;
     {
         const size_t nrun = (size_t)p.nd;
@@ -894,6 +912,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
             const int e = orole - NP;                      // 2h + {0: forecast, 1: error}
             o_which = 4 + (e & 1);
             fc_h = p.horizons[e >> 1];
+            fc_blend = SIG && ((p.blend_mask >> (e >> 1)) & 1);
             fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (e >> 1)] : __builtin_nan("");
             if (p.fcast) out_base = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w);
         }
@@ -909,7 +928,17 @@ void gibbs_sweeps_kernel(const KernelParams p)
             // forecast (src/Hmc.jl:658-667).  (pi' A^h) . mu is invariant under the label permutation, so the
             // unsorted parameters are used as they are.
             double fv;
-            if (fc_h <= FC_SPLIT_MAX) {
+            if (SIG && fc_blend) {
+                // forecastsignal (src/Hmc.jl:670-681, :908-909): the horizon equals the number of signal steps past the
+                // end date; blend of the last noisy observation and each state mean, weighted by the last step's
+                // probabilities.  noise = sigma_signal, tau = 1/noise, a = tau / (1 + tau).
+                const double tau = 1.0 / (p.sigma_signal ? p.sigma_signal[w] : 0.0);
+                const double a = tau / (1.0 + tau);
+                const double ysig = sh.y_last[(sw / p.per_sample) & 1];
+                fv = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) fv += th.pi_end[i] * (a * ysig + (1.0 - a) * th.mu[i]);
+            } else if (fc_h <= FC_SPLIT_MAX) {
                 // short horizons: the lane pair of a horizon (forecast, forecast error) meets in the middle --
                 // the even lane carries pi' A^(h/2) (as (A')^(h/2) pi), the odd lane A^(h - h/2) mu, one
                 // exchange and a dot product finish.  Half the dependent chain of the power iteration.
@@ -964,6 +993,38 @@ void gibbs_sweeps_kernel(const KernelParams p)
             // sorted views: mu[order[q]], sig2[order[q]], pib_end[order[q]], A[order[i], order[j]] (:502-513)
             const double* src = o_which == 0 ? &th.mu[0] : (o_which == 1 ? &th.sig2[0] : (o_which == 2 ? &th.pi_end[0] : &th.A[0][0]));
             val = src[o_which == 3 ? si * K + sj : si];
+            if constexpr (SIG) {
+                if (tail > 0 && o_which == 2) {
+                    // signals past the end date: report pib[end_pos,:] (:900) = pif[end_pos,:] o b, b = M_{end_pos+1} ... M_{T-1} 1
+                    // by the backward recursion b <- A (f_t o b) (backwardupdate_P!, :442-457) over the `tail` last steps
+                    double b[K];
+#pragma unroll
+                    for (int r = 0; r < K; ++r) b[r] = 1.0;
+                    for (int j = tail - 1; j >= 0; --j) {
+                        double g[K], nb[K];
+#pragma unroll
+                        for (int c = 0; c < K; ++c) g[c] = sh.ftail[j][c] * b[c];
+#pragma unroll
+                        for (int r = 0; r < K; ++r) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int c = 0; c < K; ++c) acc = fma(th.A[r][c], g[c], acc);
+                            nb[r] = acc;
+                        }
+                        rescale_pow2<K>(nb);
+#pragma unroll
+                        for (int r = 0; r < K; ++r) b[r] = nb[r];
+                    }
+                    double tot = 0.0, mine = 0.0;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) {
+                        const double g = sh.pf_rep[c] * b[c];
+                        tot += g;
+                        mine = (c == si) ? g : mine;
+                    }
+                    val = mine / tot;
+                }
+            }
         }
         if (out_base) out_base[d] = val;
         sum_acc += round5(val);
@@ -1114,6 +1175,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 }
                 if (report && p.sigvals && t >= svb && t < sve && t < T)
                     p.sigvals[((size_t)w * p.n_samples + smp) * p.nsave_ld + (t - svb)] = y[l];
+                if (t == T - 1) sh.y_last[smp & 1] = y[l];       // forecastsignal's `signal` (:909)
             }
         }
     };
@@ -1396,6 +1458,18 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 for (int s = 0; s < K; ++s) f[l][s] = ldexp(f[l][s], e);
             }
         }
+        if constexpr (SIG) {
+            if (tail > 0) {                          // emission values of the steps after end_pos, for the outputs job
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const int j = t0 + l - (T - tail);
+                    if (j >= 0 && j < tail) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) sh.ftail[j][s] = f[l][s];
+                    }
+                }
+            }
+        }
         STAMP(3);
         // local product Q = M_{t0} ... M_{t0+L-1}
         // (padded steps t >= T take part with y = 0: everything they influence lies at or beyond T,
@@ -1520,6 +1594,16 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     for (int s = 0; s < K; ++s) th.pi_end[s] = pf[l][s];
                     sh.ulast = ux[l];
                 }
+        }
+        if constexpr (SIG) {
+            if (tail > 0) {
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    if (t0 + l == T - 1 - tail) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) sh.pf_rep[s] = pf[l][s];
+                    }
+            }
         }
         if constexpr (SMOOTH) {
             // ---- backwardupdate_P! (src/Hmc.jl:442-457) as the beta recursion b_{t-1} = A (f_t o b_t), b_{T-1} = 1:

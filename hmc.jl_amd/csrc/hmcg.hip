@@ -173,6 +173,11 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
         set_err("n_samples / sigma_signal / sigvals need extras.sig_range");
         return HMCG_E_BADARG;
     }
+    if (!use_sig && (cfg->blend_mask != 0 || (ex && ex->end_pos))) {
+        set_err("blend_mask / end_pos need extras.sig_range");
+        return HMCG_E_BADARG;
+    }
+    if (cfg->blend_mask < 0 || (cfg->H < 31 && (cfg->blend_mask >> cfg->H) != 0)) { set_err("blend_mask has bits beyond H"); return HMCG_E_BADARG; }
     if (use_sig && cfg->K >= 5) { set_err("signal path: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     const Variant* v = nullptr;
     const BigVariant* bv = nullptr;
@@ -217,6 +222,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     p.kappa = cfg->kappa;
     if (ex) p.pi_smooth_mean = ex->pi_smooth_mean;
     if (ex) { p.sig_range = ex->sig_range; p.save_range = ex->save_range; p.sigma_signal = ex->sigma_signal; p.sigvals = ex->sigvals; p.nsave_ld = ex->nsave_ld; }
+    if (use_sig) { p.end_pos = ex->end_pos; p.blend_mask = cfg->blend_mask; }
     for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.window_base = cfg->window_base;
     p.alpha = cfg->alpha > 0.0 ? cfg->alpha : 1.0;
@@ -359,7 +365,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     DevBuf<int32_t> dT, dst, dxi, dxf;
     DevBuf<uint8_t> dxs;
     DevBuf<uint32_t> dwid;
-    DevBuf<int32_t> dsr, dsv;
+    DevBuf<int32_t> dsr, dsv, dep;
     DevBuf<double> dss, dsvals, dsm;
 #define ALLOC(buf, n) do { if ((buf).alloc(n) != 0) { set_err("hipMalloc of %zu elements failed", (size_t)(n)); return HMCG_E_NOMEM; } } while (0)
     ALLOC(dY, W * ld); ALLOC(dT, W); ALLOC(dst, W);
@@ -391,6 +397,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
         }
         if (extras->sig_range) { ALLOC(dsr, 2 * W); HIP_TRY(hipMemcpyAsync(dsr.p, extras->sig_range, sizeof(int32_t) * 2 * W, hipMemcpyHostToDevice, s)); dex.sig_range = dsr.p; }
         if (extras->save_range) { ALLOC(dsv, 2 * W); HIP_TRY(hipMemcpyAsync(dsv.p, extras->save_range, sizeof(int32_t) * 2 * W, hipMemcpyHostToDevice, s)); dex.save_range = dsv.p; }
+        if (extras->end_pos) { ALLOC(dep, W); HIP_TRY(hipMemcpyAsync(dep.p, extras->end_pos, sizeof(int32_t) * W, hipMemcpyHostToDevice, s)); dex.end_pos = dep.p; }
         if (extras->sigma_signal) { ALLOC(dss, W); HIP_TRY(hipMemcpyAsync(dss.p, extras->sigma_signal, sizeof(double) * W, hipMemcpyHostToDevice, s)); dex.sigma_signal = dss.p; }
         if (extras->sigvals && extras->nsave_ld > 0) {
             ALLOC(dsvals, W * nsmp * (size_t)extras->nsave_ld);

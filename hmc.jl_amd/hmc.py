@@ -129,9 +129,9 @@ def _check_live_path(opt):
     if len(sr):
         if sr != list(range(sr[0], sr[-1] + 1)) or sr[-1] != opt.sampleRange[-1]:
             raise NotImplementedError("signalRange must be a contiguous tail of sampleRange")
-        if sr[-1] != opt.endIndex:
-            raise NotImplementedError("signals reaching past endIndex (sigLen > 0, src/Hmc.jl:888,906-910) are not "
-                                      "accelerated: the reference's committed outputs only cover sigLen = 0")
+        if not 0 <= sr[-1] - opt.endIndex <= _lib.HMCG_MAXTAIL:
+            raise NotImplementedError("sigLen = last(signalRange) - endIndex (src/Hmc.jl:888) must lie in 0..%d"
+                                      % _lib.HMCG_MAXTAIL)
 
 
 def _sig_ranges(opt):
@@ -199,7 +199,12 @@ def estimatesignals(opt, device=0):
     to the next as upstream (:889-895), with HyperParams(opt): alpha = nu = 2, kappa = opt.noise (:148-159).
     Returns Samples with (noiseSamples*signalNrun) draws, sample-major, plus signalvals[Ndraws, len(signalSave)]
     and signalids[Ndraws] (1-based), as the reference's NamedTuple (:913).  The noise comes from this
-    library's counter-based RNG (site 5), not Julia's stream."""
+    library's counter-based RNG (site 5), not Julia's stream.
+
+    Signals past the end date (sigLen = last(signalRange) - endIndex > 0, :888; the len_1 / len_12 experiments of
+    code/run_hmm.jl:122-158): πb is the SMOOTHED probability at endIndex (:900); a horizon h > sigLen is forecast
+    h - sigLen steps from the window's last step (:906-907), h == sigLen goes through forecastsignal (:908-909)
+    and h < sigLen is left unset upstream (uninitialised memory) -- NaN here."""
     _check_live_path(opt)
     if not len(opt.signalRange):
         raise ValueError("estimatesignals needs a signalRange")
@@ -209,10 +214,17 @@ def estimatesignals(opt, device=0):
     Y = makey(opt)
     sig, sv = _sig_ranges(opt)
     n, ns = opt.signalNrun, opt.noiseSamples
-    res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.signalburnin, n, tuple(opt.horizons),
+    sigLen = opt.signalRange[-1] - opt.endIndex                                 # :888
+    dev_h = [h - sigLen if h > sigLen else 0 for h in opt.horizons]             # :907
+    blend = sum(1 << k for k, h in enumerate(opt.horizons) if h == sigLen and sigLen > 0)
+    unset = [k for k, h in enumerate(opt.horizons) if h < sigLen]
+    kw = dict(end_pos=[opt.endIndex - 1], blend_mask=blend) if sigLen > 0 else {}
+    res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.signalburnin, n, tuple(dev_h),
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
                                    device=device, sig_range=[sig], save_range=[sv], sigma_signal=[opt.σsignal],
-                                   kappa=opt.noise, n_samples=ns, alpha=2.0, nu=2.0)
+                                   kappa=opt.noise, n_samples=ns, alpha=2.0, nu=2.0, **kw)
+    for k in unset:
+        res["fcast"][0, 2 * k:2 * k + 2] = np.nan
     s = _unpack(res, 0, ns * n, opt.D, len(opt.horizons), enddate(opt))
     nsave = len(opt.signalSave)
     s.signalvals = np.repeat(res["sigvals"][0][:, :nsave], n, axis=0)           # :904

@@ -48,7 +48,7 @@ struct hmcg_config
     nu::Float64
     kappa::Float64
     n_samples::Int32
-    reserved1::Int32
+    blend_mask::Int32
 end
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))

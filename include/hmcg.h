@@ -51,8 +51,9 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 100
+#define HMCG_VERSION 101
 #define HMCG_MAXH 8
+#define HMCG_MAXTAIL 32         /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
 
 /* API-misuse return codes */
@@ -67,7 +68,8 @@ extern "C" {
                                     normaliser was replaced by the uniform law (reference would produce NaN and throw, src/Hmc.jl:435) */
 #define HMCG_ST_NONFINITE      4 /* non-finite observation: window skipped, outputs untouched */
 #define HMCG_ST_GAMMA_CAP      8 /* gamma rejection sampler hit its attempt cap */
-#define HMCG_ST_BAD_T         16 /* T[w] < 2, T[w] > ldY or T[w] beyond what max_T was sized for: window skipped */
+#define HMCG_ST_BAD_T         16 /* T[w] < 2, T[w] > ldY, T[w] beyond what max_T was sized for, or end_pos[w] outside
+                                      [T-1-HMCG_MAXTAIL, T-1]: window skipped */
 
 /* flags */
 #define HMCG_FLAG_RESUME 1  /* chain state (extras.xstate) is loaded instead of the makeParams init; sweep numbering continues at sweep_base */
@@ -98,7 +100,9 @@ typedef struct hmcg_config {
     int32_t n_samples;       /* opt.noiseSamples: consecutive chains of burnin+nrun sweeps, each on fresh noise, the chain
                                 state carried over (:889-895); 0 or 1 = a single chain.  Outputs then hold n_samples*nrun
                                 draws (sample-major), burnin/nrun being opt.signalburnin/opt.signalNrun */
-    int32_t reserved1;
+    int32_t blend_mask;      /* signal path: bit k set = horizon k equals sigLen and is reported through forecastsignal
+                                (src/Hmc.jl:670-681, :908-909): sum_i pi_last[i] (a Yfake[T-1] + (1-a) mu[i]), a = tau/(1+tau),
+                                tau = 1/sigma_signal[w]; horizons[k] is then ignored.  0 otherwise */
 } hmcg_config;
 
 /* Optional debug / teacher-forcing / checkpoint buffers (all may be NULL).  Pointer
@@ -117,13 +121,17 @@ typedef struct hmcg_extras {
     const uint32_t* window_ids; /* [W] explicit RNG stream ids (NULL: window_base + w); lets a sharded /
                                    load-balanced run reproduce the unsharded one window for window */
     /* signal path (all NULL for estimatemodel).  Positions are 0-based and window-relative. */
-    const int32_t* sig_range;   /* [W][2] signal positions [begin, end): opt.signalRange; end must equal T[w]
-                                   (signals reaching past endIndex, sigLen > 0, are not supported) */
+    const int32_t* sig_range;   /* [W][2] signal positions [begin, end): opt.signalRange; end must equal T[w] */
     const int32_t* save_range;  /* [W][2] positions reported in sigvals: opt.signalSave */
     const double* sigma_signal; /* [W] opt.sigma_signal: sd of the N(0,1) noise added to the signal positions (:892) */
     double* sigvals;            /* [W][n_samples][nsave_ld] Yfake[signalSave] of every noise sample (:904) */
     int32_t nsave_ld;
     int32_t reserved2;
+    const int32_t* end_pos;     /* [W] signal path, optional: position (opt.endIndex - 1) whose SMOOTHED probabilities are
+                                   reported in pi_end when the window carries sigLen = T-1-end_pos signal steps past the end
+                                   date (samples.pib[:, opt.endIndex, :], src/Hmc.jl:888,900); 0 <= sigLen <= HMCG_MAXTAIL.
+                                   NULL: the last step.  Forecasts always start from the last step (:907,909): pass
+                                   horizons[k] = h - sigLen, or set blend_mask for h == sigLen */
     double* pi_smooth_mean;     /* [W][ldY][K] optional: mean over the kept draws of the SMOOTHED probabilities
                                    P(X_t | Y_1:T, theta) in sorted labels = the draw-average of the reference's
                                    samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  K <= 3 variants;

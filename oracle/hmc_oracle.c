@@ -534,18 +534,26 @@ int hmco_estimate_window_ex(const double *Y, int T, int K, int burnin, int nrun,
                             uint64_t seed, uint32_t window_id, int flags, const int *x_init,
                             int sig_b, int sig_e, double kappa, double alpha, double nu,
                             int n_samples, double sigma_signal, int save_b, int save_e,
+                            int end_pos, int blend_mask,
                             double *mu, double *sig2, double *A, double *pi_end, double *fcast,
                             double *pi_smooth, double *summary, double *sigvals,
                             int *x_final, double *pif_final, int *status)
 {
+    /* end_pos: 0-based position whose SMOOTHED state probabilities are reported as pi_end -- the reference's
+     * samples.pib[:, opt.endIndex, :] (:900) when the window carries sigLen = T-1-end_pos signal steps past the
+     * end date (:888); negative or T-1 = the last step (smoothed == filtered there).
+     * blend_mask bit k: horizon k equals sigLen and is reported through forecastsignal (:670-681, :908-909)
+     * with signal = Yfake[T-1] and noise = sigma_signal; the other horizons go through forecast() with the
+     * horizon the caller passes (h - sigLen, :906-907), always from the LAST step's probabilities. */
     if (K < 1 || K > HMCO_MAXK || T < 2 || H < 0 || H > HMCO_MAXH || nrun < 0 || burnin < 0 || n_samples < 1) return -1;
-    if (sig_b < sig_e && (sig_b < 0 || sig_e != T)) return -1;       /* only sigLen = 0 */
+    if (sig_b < sig_e && (sig_b < 0 || sig_e != T)) return -1;       /* the signal set is a tail of the window */
+    const int rep_pos = (end_pos >= 0 && end_pos < T - 1) ? end_pos : T - 1;
     chain_t c;
     memset(&c, 0, sizeof c);
     c.K = K; c.T = T;
     c.faithful_cost = flags & 1;
     c.sig_b = sig_b < sig_e ? sig_b : T; c.sig_e = sig_b < sig_e ? sig_e : T; c.kappa = kappa;
-    int smoother = (flags & 2) || pi_smooth != NULL;
+    int smoother = (flags & 2) || pi_smooth != NULL || rep_pos != T - 1;
     for (int t = 0; t < T; ++t) if (!isfinite(Y[t])) { if (status) *status = ST_NONFINITE; return 0; }
     double *Yfake = (double *)malloc(sizeof(double) * (size_t)T);
     memcpy(Yfake, Y, sizeof(double) * (size_t)T);                   /* Yfake = deepcopy(Yreal) (:887) */
@@ -579,20 +587,28 @@ int hmco_estimate_window_ex(const double *Y, int T, int K, int burnin, int nrun,
             double pe[HMCO_MAXK], arow[HMCO_MAXK * HMCO_MAXK];
             for (int k = 0; k < K; ++k) {
                 pe[k] = PIF(&c, T - 1, order[k]);      /* pib[end,:] == sorted pif[end,:] (:448,:513) */
+                const double prep = rep_pos == T - 1 ? pe[k] : PIB(&c, rep_pos, order[k]);     /* :900 */
                 if (mu) mu[(size_t)k * nd + d] = c.mu[k];
                 if (sig2) sig2[(size_t)k * nd + d] = c.sig2[k];
-                if (pi_end) pi_end[(size_t)k * nd + d] = pe[k];
+                if (pi_end) pi_end[(size_t)k * nd + d] = prep;
                 acc[k] += round5(c.mu[k]);
                 acc[K + k] += round5(c.sig2[k]);
-                acc[2 * K + k] += round5(pe[k]);
+                acc[2 * K + k] += round5(prep);
             }
             for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
                 arow[i * K + j] = c.A[i][j];
                 if (A) A[((size_t)j * K + i) * nd + d] = c.A[i][j];
                 acc[3 * K + j * K + i] += round5(c.A[i][j]);
             }
-            for (int h = 0; h < H; ++h) {                                             /* :860-862, :905-907 (sigLen = 0) */
-                double f = hmco_forecast(K, c.mu, arow, pe, horizons[h]);
+            for (int h = 0; h < H; ++h) {                                             /* :860-862, :905-910 */
+                double f;
+                if ((blend_mask >> h) & 1) {                                          /* forecastsignal (:670-681) */
+                    const double tau = 1.0 / sigma_signal, a = tau / (1.0 + tau);
+                    f = 0.0;
+                    for (int k = 0; k < K; ++k) f += pe[k] * (a * Yfake[T - 1] + (1.0 - a) * c.mu[k]);
+                } else {
+                    f = hmco_forecast(K, c.mu, arow, pe, horizons[h]);
+                }
                 double e = f - (yreal ? yreal[h] : NAN);
                 if (fcast) { fcast[(size_t)(2 * h) * nd + d] = f; fcast[(size_t)(2 * h + 1) * nd + d] = e; }
                 acc[3 * K + K * K + 2 * h] += round5(f);
@@ -619,7 +635,7 @@ int hmco_estimate_window(const double *Y, int T, int K, int burnin, int nrun,
                          int *x_final, double *pif_final, int *status)
 {
     return hmco_estimate_window_ex(Y, T, K, burnin, nrun, horizons, H, yreal, seed, window_id, flags, x_init,
-                                   T, T, 1.0, 1.0, 1.0, 1, 0.0, 0, 0,
+                                   T, T, 1.0, 1.0, 1.0, 1, 0.0, 0, 0, -1, 0,
                                    mu, sig2, A, pi_end, fcast, pi_smooth, summary, NULL, x_final, pif_final, status);
 }
 

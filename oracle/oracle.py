@@ -88,11 +88,13 @@ def estimate_window(Y, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, w
 
 
 def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alpha=1.0, nu=1.0, sigma_signal=0.0,
-                     save=(0, 0), horizons=(12,), yreal=None, seed=1234, window_id=0, x_init=None):
+                     save=(0, 0), horizons=(12,), yreal=None, seed=1234, window_id=0, x_init=None, end_pos=-1,
+                     blend_mask=0):
     """estimatesignals!'s sampling loop (src/Hmc.jl:868-914) for one window; with n_samples=1 and
     sigma_signal=0 it is the base estimatemodel run on a window that has a signal set.
-    sig/save are 0-based half-open position ranges.  Returns draws as (n_samples*nrun, ...) arrays
-    plus sigvals (n_samples, nsave)."""
+    sig/save are 0-based half-open position ranges.  end_pos (0-based) selects the position whose smoothed
+    probabilities are reported as pi_end (:900; default the last step), blend_mask the horizons reported through
+    forecastsignal (:908-909).  Returns draws as (n_samples*nrun, ...) arrays plus sigvals (n_samples, nsave)."""
     Y = np.ascontiguousarray(Y, dtype=np.float64)
     T = Y.shape[0]
     H = len(horizons)
@@ -111,7 +113,8 @@ def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alp
                                        _p(hz, _ip), C.c_int(H), _p(yr), C.c_uint64(seed), C.c_uint32(window_id),
                                        C.c_int(0), _p(xi, _ip), C.c_int(sig[0]), C.c_int(sig[1]), C.c_double(kappa),
                                        C.c_double(alpha), C.c_double(nu), C.c_int(n_samples), C.c_double(sigma_signal),
-                                       C.c_int(save[0]), C.c_int(save[1]), _p(mu), _p(sig2), _p(A), _p(pe), _p(fc),
+                                       C.c_int(save[0]), C.c_int(save[1]), C.c_int(end_pos), C.c_int(blend_mask),
+                                       _p(mu), _p(sig2), _p(A), _p(pe), _p(fc),
                                        None, _p(summ), _p(sv), _p(xf, _ip), _p(pf), C.byref(st))
     if rc != 0:
         raise ValueError("hmco_estimate_window_ex rc=%d" % rc)

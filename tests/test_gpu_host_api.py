@@ -80,6 +80,37 @@ def test_estimatesignals_like_run_hmm_allsignal(hmclib, oracle, inflation, tmp_p
     assert lines[1].startswith("1980-01-01,1,") and lines[-1].startswith("1980-01-01,5,")
 
 
+@pytest.mark.parametrize("signalLen", [1, 12])
+def test_estimatesignals_like_run_hmm_future_signals(hmclib, oracle, inflation, signalLen):
+    """code/run_hmm.jl:122-156 (the len_1 / len_12 experiments): the window runs signalLen months past the end date
+    and those months are the signals.  h = 12 is forecastsignal for signalLen 12 and a 11-step forecast for
+    signalLen 1; h = 6 < 12 is unset upstream (NaN here); h = 24 is forecast 24 - signalLen steps ahead."""
+    y, dates = inflation
+    dd = [dt.date.fromisoformat(d) for d in dates]
+    e = 200
+    opt = hmc.estopt(y, dd, sampleRange=range(1, e + signalLen + 1), signalRange=range(e + 1, e + signalLen + 1),
+                     signalSave=range(e + 1, e + signalLen + 1), endIndex=e, horizons=[6, 12, 24], D=3, burnin=100, Nrun=200,
+                     signalburnin=10, signalNrun=25, noiseSamples=4, noise=1.0, series="official")
+    s = hmc.estimatesignals(opt)
+    T = e + signalLen
+    base = oracle.estimate_signals(y[:T], 3, 100, 200, 1, sig=(e, T), kappa=1.0, alpha=1.0, nu=1.0, horizons=(6, 12, 24),
+                                   yreal=[y[e + 5], y[e + 11], y[e + 23]])
+    assert abs(base["sig2"].mean() * 1.0 - opt.σsignal) < 1e-9 * (1 + opt.σsignal)
+    dev_h = [h - signalLen if h > signalLen else 0 for h in (6, 12, 24)]
+    blend = 2 if signalLen == 12 else 0
+    o = oracle.estimate_signals(y[:T], 3, 10, 25, 4, sig=(e, T), kappa=1.0, alpha=2.0, nu=2.0, sigma_signal=opt.σsignal,
+                                save=(e, T), horizons=dev_h, yreal=[y[e + 5], y[e + 11], y[e + 23]], end_pos=e - 1,
+                                blend_mask=blend)
+    assert s.forecasts.shape == (100, 6) and s.signalvals.shape == (100, signalLen)
+    assert np.max(np.abs(s.μ - o["mu"])) < 1e-9 and np.max(np.abs(s.πb[:, -1, :] - o["pi_end"])) < 1e-9
+    if signalLen == 12:
+        assert np.isnan(s.forecasts[:, 0:2]).all()                         # h = 6 < sigLen: never assigned upstream
+        assert np.max(np.abs(s.forecasts[:, 2:] - o["fcast"][:, 2:])) < 1e-9
+    else:
+        assert np.max(np.abs(s.forecasts - o["fcast"])) < 1e-9
+    assert np.max(np.abs(s.signalvals[::25] - o["sigvals"])) < 1e-9
+
+
 @pytest.mark.parametrize("noise", ["0.1", "0.6"])
 def test_gpu_signal_path_vs_reference_dispersion_outputs(hmclib, inflation, noise):
     """The GPU chain against the reference's committed allsignal dispersion outputs (see the oracle test of the

@@ -135,6 +135,46 @@ def test_signal_path_partial_signal_synthetic(hmclib, oracle):
         check_signals_against_oracle(oracle, Y, Tw, K, 3, 8, 3, sig, save, 0.6, 2.0, 2.0, np.array([0.5, 1.0, 0.2]), fut[:, 11:12])
 
 
+@pytest.mark.parametrize("K,T,sigLen", [(3, 300, 1), (3, 1000, 12), (2, 200, 3), (3, 140, 32)])
+def test_signal_path_signals_past_the_end_date(hmclib, oracle, K, T, sigLen):
+    """estimatesignals! with sigLen = last(signalRange) - endIndex > 0 (src/Hmc.jl:888; the len_1 / len_12 runs of
+    code/run_hmm.jl:122-158): pi_end reports the smoothed probabilities at endIndex (:900), horizon sigLen goes
+    through forecastsignal (:908-909), a longer one is forecast h - sigLen steps from the last step (:906-907).
+    No committed reference output covers this case: pinned by the oracle restatement only."""
+    W = 3
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    Tw = np.array([T, T - 7, T - 64 if T > 200 else T - 1], dtype=np.int32)
+    sig = np.stack([Tw - sigLen, Tw], axis=1).astype(np.int32)
+    save = sig.copy()
+    end_pos = (Tw - 1 - sigLen).astype(np.int32)
+    ssig = np.array([0.4, 1.3, 0.05])
+    horizons = (0, 12)                           # device horizons: slot 0 is the blend (h == sigLen), slot 1 is h = sigLen + 12
+    yreal = np.stack([fut[:, 0], fut[:, 11]], axis=1)
+    g = _lib.estimate_batch_host(Y, Tw, K, 4, 10, horizons, yreal, want_state=True, sig_range=sig, save_range=save,
+                                 sigma_signal=ssig, kappa=0.6, n_samples=3, alpha=2.0, nu=2.0, end_pos=end_pos, blend_mask=1)
+    for w in range(W):
+        o = oracle.estimate_signals(Y[w, :Tw[w]], K, 4, 10, 3, sig=tuple(sig[w]), kappa=0.6, alpha=2.0, nu=2.0,
+                                    sigma_signal=float(ssig[w]), save=tuple(save[w]), horizons=horizons, yreal=yreal[w],
+                                    window_id=w, end_pos=int(end_pos[w]), blend_mask=1)
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"])
+        for k, go in (("mu", g["mu"][w].T), ("sig2", g["sig2"][w].T), ("pi_end", g["pi_end"][w].T), ("fcast", g["fcast"][w].T)):
+            assert close(go, o[k]) < TOL, (w, k)
+        assert close(g["summary"][w], o["summary"]) < TOL
+        assert close(g["sigvals"][w][:, :sigLen], o["sigvals"]) < TOL
+        assert np.max(np.abs(g["pi_end"][w].sum(axis=0) - 1)) < 1e-12
+    # end_pos at the last step is the plain path, bit for bit
+    a = _lib.estimate_batch_host(Y, Tw, K, 4, 10, (12,), yreal[:, 1:], sig_range=sig, sigma_signal=ssig, kappa=0.6, n_samples=2,
+                                 end_pos=Tw - 1)
+    b = _lib.estimate_batch_host(Y, Tw, K, 4, 10, (12,), yreal[:, 1:], sig_range=sig, sigma_signal=ssig, kappa=0.6, n_samples=2)
+    for k in ("mu", "pi_end", "fcast", "summary"):
+        assert np.array_equal(a[k], b[k]), k
+    # a tail longer than HMCG_MAXTAIL is flagged, not computed
+    bad = _lib.estimate_batch_host(Y, Tw, K, 1, 2, (12,), yreal[:, 1:], sig_range=sig, sigma_signal=ssig, kappa=0.6,
+                                   end_pos=Tw - 1 - (_lib.HMCG_MAXTAIL + 1))
+    assert (bad["status"] == _lib.ST_BAD_T).all()
+
+
 @pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64, 5]), (2, [300, 2, 129])])
 def test_smoothed_probabilities_mean(hmclib, oracle, K, lens):
     """Optional output: the draw-average of the smoothed probabilities pib[:, t, :] (backwardupdate_P!,

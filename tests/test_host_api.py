@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = hmc_jl_amd.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hmcg_version() == 100
+    assert lib.hmcg_version() == int(re.search(r"#define HMCG_VERSION (\d+)", hdr).group(1))
 
 
 def test_no_cpu_fallback_and_struct_validation():
@@ -60,8 +60,12 @@ def test_estopt_defaults_and_accessors():
     assert hmc.yobs(o, 133) == 133.0 and hmc.yend(o, 2) == 123.0
     o2 = hmc.estopt(raw, dates, sampleRange=range(1, 51), signalRange=range(49, 51), endIndex=48)
     assert o2.obsRange == list(range(1, 49))
+    o3 = hmc.estopt(raw, dates, sampleRange=range(1, 101), signalRange=range(60, 101), endIndex=60)   # sigLen = 40 > HMCG_MAXTAIL
     with pytest.raises(NotImplementedError):
-        hmc.estimatemodel(o2)
+        hmc.estimatemodel(o3)
+    o4 = hmc.estopt(raw, dates, sampleRange=range(1, 51), signalRange=range(40, 45), endIndex=50)     # not a tail of the window
+    with pytest.raises(NotImplementedError):
+        hmc.estimatemodel(o4)
 
 
 def test_forecast_host_helper(oracle):
@@ -126,3 +130,17 @@ def test_partition_windows():
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert shard.contiguous_blocks(10, 4) == [[0, 1], [2, 3, 4], [5, 6], [7, 8, 9]]
     assert shard.partition_windows([1000] * 8, 4) == [[0, 4], [1, 5], [2, 6], [3, 7]]
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The Python mirror of hmcg_config / hmcg_extras / hmcg_timing has the C compiler's sizes."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%d %%d", sizeof(hmcg_config), '
+                   'sizeof(hmcg_extras), sizeof(hmcg_timing), HMCG_MAXH, HMCG_MAXTAIL);return 0;}\n'
+                   % os.path.join(ROOT, "include", "hmcg.h"))
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_lib.Config), C.sizeof(_lib.Extras), C.sizeof(_lib.Timing), _lib.HMCG_MAXH, _lib.HMCG_MAXTAIL]
