@@ -383,3 +383,113 @@ def write_summaries(summary, opts, dir, legacy_trans_header=False):
                 f.write(",".join([str(enddate(opts[w]))] + [_fmt(v) for v in summary[w, a:b]]) + "\n")
         paths.append(p)
     return paths
+
+
+# ------------------------------------------- aggregation over per-draw CSVs (host) --
+# runaggregate / calcdispersion (src/Hmc.jl:1025-1092) work on the CSV files saveresults wrote, exactly as
+# upstream: they are file-in / file-out and never touch the GPU.  For the estimatemodel path the on-device
+# `summary` block (write_summaries above) gives the same numbers without the per-draw files.
+
+def _read_csv(path):
+    import csv
+    with open(path, newline="") as f:
+        rows = list(csv.reader(f))
+    return rows[0], rows[1:]
+
+
+def _seq_mean(vals):
+    s = 0.0
+    for v in vals:
+        s += v
+    return s / len(vals) if vals else float("nan")
+
+
+def _seq_std(vals):
+    """Statistics.std: corrected (n-1) two-pass sample standard deviation."""
+    n = len(vals)
+    if n < 2:
+        return float("nan")
+    m = _seq_mean(vals)
+    s = 0.0
+    for v in vals:
+        s += (v - m) * (v - m)
+    return (s / (n - 1)) ** 0.5
+
+
+def _aggregate(header, rows, groups, funcs):
+    """DataFrames.aggregate(df, groups, funcs): one row per group in order of first appearance; columns = groups,
+    then for each function all non-group columns named <col>_<fname>."""
+    gi = [header.index(g) for g in groups]
+    vi = [i for i in range(len(header)) if i not in gi]
+    order, buckets = [], {}
+    for r in rows:
+        key = tuple(r[i] for i in gi)
+        if key not in buckets:
+            buckets[key] = []
+            order.append(key)
+        buckets[key].append([float(r[i]) for i in vi])
+    out_header = list(groups) + ["%s_%s" % (header[i], name) for name, _ in funcs for i in vi]
+    out = []
+    for key in order:
+        cols = list(zip(*buckets[key]))
+        out.append(list(key) + [_fmt(fn(list(c))) for _, fn in funcs for c in cols])
+    return out_header, out
+
+
+def _write_csv(path, header, rows):
+    with open(path, "w") as f:
+        f.write(",".join(header) + "\n")
+        for r in rows:
+            f.write(",".join(r) + "\n")
+
+
+def runaggregate(datadir, var=None):
+    """runaggregate(datadir) / runaggregate(datadir, var) (src/Hmc.jl:1025-1078): `<var>_summary.csv` = the mean of
+    every column of each per-draw file `<var>_<date>.csv`, one row per date -- or per (date, signal) when the files
+    carry signal columns.  As upstream, the one-argument form groups signal files by :signal_1 and the two-argument
+    form by :signalid (the committed `forecasts_summary.csv` fixtures come from the latter)."""
+    import glob
+    if not os.path.isdir(datadir):
+        raise ValueError("%s is not a valid directory" % datadir)
+    first = sorted(glob.glob(os.path.join(datadir, "filtered_means*")))
+    first = [f for f in first if "summary" not in f and "dispersion" not in f]
+    hassignal = bool(first) and any("signal" in h for h in _read_csv(first[0])[0])
+    groups = ["date"] if not hassignal else (["date", "signal_1"] if var is None else ["date", "signalid"])
+    written = []
+    for v in (SUMMARY_FILES_UPSTREAM_ORDER if var is None else (var,)):
+        files = sorted(f for f in glob.glob(os.path.join(datadir, v + "*")) if "summary" not in f and "dispersion" not in f)
+        if not files:
+            continue
+        out_header, out_rows = None, []
+        for f in files:
+            header, rows = _read_csv(f)
+            h, r = _aggregate(header, rows, groups, [("mean", _seq_mean)])
+            out_header = out_header or h
+            out_rows += r
+        path = os.path.join(datadir, v + "_summary.csv")
+        _write_csv(path, out_header, out_rows)
+        written.append(path)
+    return written
+
+
+SUMMARY_FILES_UPSTREAM_ORDER = ("filtered_means", "filtered_state_probs", "filtered_variances", "filtered_trans_probs", "forecasts")
+
+
+def calcdispersion(datadir):
+    """calcdispersion(datadir) (src/Hmc.jl:1080-1092): for each `<var>_summary.csv`, strip `_mean` from the column
+    names and write mean and (n-1) standard deviation of every column per date to `<var>_dispersion.csv`
+    (columns: date, all <col>_mean, then all <col>_std -- the signal id included, as upstream)."""
+    if not os.path.isdir(datadir):
+        raise ValueError("%s is not a valid directory" % datadir)
+    written = []
+    for v in SUMMARY_FILES_UPSTREAM_ORDER:
+        src = os.path.join(datadir, v + "_summary.csv")
+        if not os.path.exists(src):
+            continue
+        header, rows = _read_csv(src)
+        header = [h.replace("_mean", "") for h in header]
+        h, r = _aggregate(header, rows, ["date"], [("mean", _seq_mean), ("std", _seq_std)])
+        path = os.path.join(datadir, v + "_dispersion.csv")
+        _write_csv(path, h, r)
+        written.append(path)
+    return written

@@ -144,3 +144,57 @@ def test_ctypes_structs_match_the_header(tmp_path):
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [C.sizeof(_lib.Config), C.sizeof(_lib.Extras), C.sizeof(_lib.Timing), _lib.HMCG_MAXH, _lib.HMCG_MAXTAIL]
+
+
+def test_calcdispersion_reproduces_reference_dispersion_text(tmp_path):
+    """calcdispersion (src/Hmc.jl:1080-1092) on the head of the reference's committed
+    signals_official_noise_0.3_allsignal/forecasts_summary.csv (5 dates x 100 signal ids) must give the first rows of
+    its committed forecasts_dispersion.csv character for character (header, CSV.jl float text, n-1 std).
+    On the full 45 500-row file 453 of 456 lines are identical and 3 differ in the last digit (summation order)."""
+    import shutil
+    g = os.path.join(ROOT, "tests", "golden")
+    shutil.copy(os.path.join(g, "signals_noise_0.3_allsignal_forecasts_summary_head.csv"), tmp_path / "forecasts_summary.csv")
+    out = hmc.calcdispersion(str(tmp_path))
+    assert [os.path.basename(p) for p in out] == ["forecasts_dispersion.csv"]
+    got = open(out[0]).read().splitlines()
+    exp = open(os.path.join(g, "signals_noise_0.3_allsignal_forecasts_dispersion.csv")).read().splitlines()[:6]
+    assert got == exp
+
+
+def test_runaggregate_layouts(tmp_path):
+    """runaggregate (src/Hmc.jl:1025-1078) over per-draw files written by basicsave: plain files group by date,
+    signal files by (date, signal_1) in the one-argument form and by (date, signalid) in the two-argument form."""
+    rng = np.random.default_rng(5)
+    plain, sigd = tmp_path / "plain", tmp_path / "sig"
+    plain.mkdir(); sigd.mkdir()
+    dates = [dt.date(1980, 1, 1), dt.date(1980, 2, 1)]
+    data = {}
+    for d in dates:
+        x = rng.normal(size=(6, 3))
+        data[d] = np.rint(x * 1e5) / 1e5
+        for name in ("filtered_means", "forecasts"):
+            hmc.basicsave(x, [d] * 6, str(plain / ("%s_%s.csv" % (name, d))), ["state_1", "state_2", "state_3"])
+        sig = np.repeat(np.array([[1.5, 2.5], [3.25, 4.0]]), 3, axis=0)
+        hmc.basicsave(x, [d] * 6, str(sigd / ("filtered_means_%s.csv" % d)), ["state_1", "state_2", "state_3"],
+                      signal=sig, signalids=[1, 1, 1, 2, 2, 2])
+    out = hmc.runaggregate(str(plain))
+    assert sorted(os.path.basename(p) for p in out) == ["filtered_means_summary.csv", "forecasts_summary.csv"]
+    lines = open(plain / "filtered_means_summary.csv").read().splitlines()
+    assert lines[0] == "date,state_1_mean,state_2_mean,state_3_mean" and len(lines) == 3
+    vals = np.array([[float(v) for v in l.split(",")[1:]] for l in lines[1:]])
+    assert np.max(np.abs(vals - np.array([data[d].mean(axis=0) for d in dates]))) < 1e-15
+    hmc.runaggregate(str(sigd), "filtered_means")
+    lines = open(sigd / "filtered_means_summary.csv").read().splitlines()
+    assert lines[0] == "date,signalid,state_1_mean,state_2_mean,state_3_mean,signal_1_mean,signal_2_mean" and len(lines) == 5
+    assert lines[1].startswith("1980-01-01,1,") and lines[2].startswith("1980-01-01,2,") and lines[2].endswith(",3.25,4")
+    hmc.runaggregate(str(sigd))                               # upstream's one-argument form groups by signal_1
+    lines = open(sigd / "filtered_means_summary.csv").read().splitlines()
+    assert lines[0] == "date,signal_1,signalid_mean,state_1_mean,state_2_mean,state_3_mean,signal_2_mean"
+    assert lines[1].startswith("1980-01-01,1.5,1,")
+    # and the dispersion of the two-argument summary: mean and n-1 std over the signal ids of a date
+    hmc.runaggregate(str(sigd), "filtered_means")
+    hmc.calcdispersion(str(sigd))
+    lines = open(sigd / "filtered_means_dispersion.csv").read().splitlines()
+    assert lines[0].startswith("date,signalid_mean,state_1_mean") and lines[0].endswith("signal_1_std,signal_2_std")
+    row = [float(v) for v in lines[1].split(",")[1:]]
+    assert row[0] == 1.5 and abs(row[6] - np.std([1.0, 2.0], ddof=1)) < 1e-15
