@@ -169,7 +169,7 @@ def main():
                        "helper_waves": tm.helper_waves, "lds_bytes_per_window": tm.lds_bytes, "windows_flagged": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hmcg::gibbs_sweeps_kernel<3,%d,%d,false,false,%d>" % (tm.steps_per_thread, tm.threads_per_window, tm.helper_waves),
+                         "kernel": "hmcg::gibbs_sweeps_kernel<3,%d,%d,false,false,%d,2>" % (tm.steps_per_thread, tm.threads_per_window, tm.helper_waves),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": B * W_PER_GPU * DRAWS,
                          "note": "algorithmic bytes = 58160 B/draw (SURVEY 8d) x 256 windows x 1000 draws; the chain "
                                  "state is register/LDS-resident, so the physical limiter is fp64 VALU latency, not HBM"},
