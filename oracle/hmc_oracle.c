@@ -20,7 +20,12 @@
  *   - what IS pinned: (1) the committed posterior summaries
  *     data/output/official/\*_summary.csv (tests/golden/official_*), statistically;
  *     (2) the reference unit test's truth-recovery tolerances (test/runtests.jl:56-57);
- *     (3) hand-derived known-answer vectors for each deterministic kernel.
+ *     (3) hand-derived known-answer vectors for each deterministic kernel;
+ *     (4) for the signal path (estimatesignals!, :868-914) the committed allsignal dispersion outputs
+ *     (tests/golden/signals_noise_*).
+ *   - signals past the end date (sigLen > 0, :888,:900,:906-910 -- end_pos / blend_mask of
+ *     hmco_estimate_window_ex) have no committed reference output: "parity unpinned" for that sub-case
+ *     beyond the line-by-line restatement and the consistency checks in tests/.
  *
  * RNG SPEC (shared, by restatement, with the HIP path so that seeded chains agree
  * draw for draw): Philox4x32-10, key = 64-bit seed, counter = (index,
