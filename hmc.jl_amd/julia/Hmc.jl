@@ -10,8 +10,10 @@
 # has a `julia` binary.  The tested host layer with the same surface is hmc.jl_amd/hmc.py; the C ABI
 # it shares with this file is what the parity tests exercise.
 #
-# Not wired here yet (available through the C ABI and the Python host layer): the signal Monte-Carlo path
-# (estimatesignals!, hmcg_extras.sig_range/...), explicit window ids, checkpoint/resume.
+# Wired: estimatemodel, estimatewindows (batched), estimatesignals! (signal Monte-Carlo path incl. signals past the
+# end date), saveresults with and without signals.  Not wired here (available through the C ABI and the Python
+# host layer): explicit window ids, checkpoint/resume, the smoothed-probability output.  runaggregate /
+# calcdispersion of the reference work unchanged on the files written here (same names, columns and float text).
 #
 # Reference lines mirrored: estopt src/Hmc.jl:17-73, accessors :85-107, makedate :573-582,
 # forecast :658-667, basicsave/saveresults :707-748, estimatemodel :850-865.
@@ -50,6 +52,26 @@ struct hmcg_config
     n_samples::Int32
     blend_mask::Int32
 end
+
+struct hmcg_extras
+    struct_size::Int32
+    reserved::Int32
+    x_init::Ptr{Int32}
+    x_final::Ptr{Int32}
+    pif_final::Ptr{Float64}
+    xstate::Ptr{UInt8}
+    sumacc::Ptr{Float64}
+    window_ids::Ptr{UInt32}
+    sig_range::Ptr{Int32}
+    save_range::Ptr{Int32}
+    sigma_signal::Ptr{Float64}
+    sigvals::Ptr{Float64}
+    nsave_ld::Int32
+    reserved2::Int32
+    end_pos::Ptr{Int32}
+    pi_smooth_mean::Ptr{Float64}
+end
+const HMCG_MAXTAIL = 32
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))
 device_count() = Int(ccall((:hmcg_device_count, LIBHMCG), Cint, ()))
@@ -103,10 +125,16 @@ function forecast(μ, A, πb, horizon, Yreal)
 end
 
 # ---- the ccall ---------------------------------------------------------------------------
-function _check_live(opt::estopt)
-    isempty(opt.signalRange) || error("signal ranges (estimatesignals!) are outside the accelerated path")
+function _check_live(opt::estopt; signals::Bool=false)
+    (signals || isempty(opt.signalRange)) || error("this entry takes windows without signals; use estimatesignals!")
     (first(opt.sampleRange) == 1 && collect(opt.sampleRange) == collect(1:last(opt.sampleRange))) ||
         error("sampleRange must be 1:N (src/Hmc.jl indexes window-relative arrays with absolute indices)")
+    if !isempty(opt.signalRange)
+        sr = collect(opt.signalRange)
+        (sr == collect(first(sr):last(sr)) && last(sr) == last(opt.sampleRange)) ||
+            error("signalRange must be a contiguous tail of sampleRange")
+        0 <= last(sr) - opt.endIndex <= HMCG_MAXTAIL || error("sigLen = last(signalRange) - endIndex must lie in 0..$(HMCG_MAXTAIL)")
+    end
 end
 
 _yreal(opt::estopt) = [opt.endIndex + h <= length(opt.rawdata) ? opt.rawdata[opt.endIndex + h] : NaN for h in opt.horizons]
@@ -171,6 +199,72 @@ end
 """
 estimatemodel(opt::estopt; device::Integer=0) = estimatewindows([opt]; device=device)[1][1]
 
+# One window on the signal path: n_samples chained noise samples of (burnin + nrun) sweeps (src/Hmc.jl:889-912).
+function _signal_call(opt::estopt, burnin, nrun, n_samples, σsignal, κ, α, ν, devh::Vector{Int}, blend::Integer, endpos; device::Integer=0)
+    Y = makey(opt); T = Int32[length(Y)]; K = opt.D; H = length(opt.horizons); nd = n_samples * nrun
+    hz = ntuple(i -> i <= H ? Int32(devh[i]) : Int32(0), HMCG_MAXH)
+    cfg = Ref(hmcg_config(Int32(sizeof(hmcg_config)), 1, K, length(Y), length(Y), burnin, nrun, H, hz, UInt64(opt.seed),
+                          UInt32(0), Int32(device), Int32(0), Int32(0), Int32(0), Int32(0), Float64(α), Float64(ν), Float64(κ),
+                          Int32(n_samples), Int32(blend)))
+    sig = Int32[first(opt.signalRange) - 1, last(opt.signalRange)]                 # 0-based [begin, end)
+    nsave = length(opt.signalSave)
+    sv = nsave > 0 ? Int32[first(opt.signalSave) - 1, last(opt.signalSave)] : Int32[0, 0]
+    ssig = Float64[σsignal]
+    sigvals = zeros(Float64, max(nsave, 1), n_samples)                             # C: [n_samples][nsave_ld]
+    ep = Int32[endpos]
+    yreal = _yreal(opt)
+    μ = Array{Float64}(undef, nd, K); σ = similar(μ); πe = similar(μ)
+    A = Array{Float64}(undef, nd, K, K); fc = Array{Float64}(undef, nd, 2H); st = zeros(Int32, 1)
+    rc = GC.@preserve Y T yreal μ σ A πe fc st sig sv ssig sigvals ep begin
+        ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
+                             pointer(sig), pointer(sv), pointer(ssig), pointer(sigvals), Int32(max(nsave, 1)), Int32(0),
+                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL))
+        ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
+              (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{hmcg_extras}, Ptr{Cvoid}),
+              cfg, Y, T, H > 0 ? pointer(yreal) : Ptr{Float64}(C_NULL), μ, σ, A, πe, fc, C_NULL, st, ex, C_NULL)
+    end
+    rc == 0 || error("libhmcgibbs rc=$rc: $(last_error())")
+    return μ, σ, πe, A, fc, sigvals
+end
+
+"""
+    estimatesignals!(opt) -> (μ, σ, πb, A, forecasts, obsdates, signalvals, signalids)      (src/Hmc.jl:868-914)
+
+Sets `opt.σsignal` from a base run when it is 0 (`:869-872`; upstream runs that one with HyperParams(Y, D): κ = 1,
+α = ν = 1).  `πb` is (Ndraws, D) as upstream (`:900`).  Noise comes from the library's counter-based RNG.
+"""
+function estimatesignals!(opt::estopt; device::Integer=0)
+    _check_live(opt; signals=true)
+    isempty(opt.signalRange) && error("estimatesignals! needs a signalRange")
+    H = length(opt.horizons)
+    if isapprox(opt.σsignal, 0)
+        _, σb, _, _, _, _ = _signal_call(opt, opt.burnin, opt.Nrun, 1, 0.0, 1.0, 1.0, 1.0, collect(Int, opt.horizons), 0, -1; device=device)
+        opt.σsignal = sum(σb) / length(σb) * opt.noise
+    end
+    sigLen = last(opt.signalRange) - opt.endIndex                                   # :888
+    devh = [h > sigLen ? h - sigLen : 0 for h in opt.horizons]                     # :907
+    blend = sigLen > 0 ? sum(Int[(1 << (k - 1)) for (k, h) in enumerate(opt.horizons) if h == sigLen]) : 0
+    μ, σ, πe, A, fc, sigvals = _signal_call(opt, opt.signalburnin, opt.signalNrun, opt.noiseSamples, opt.σsignal, opt.noise,
+                                            2.0, 2.0, devh, blend, sigLen > 0 ? opt.endIndex - 1 : -1; device=device)
+    for (k, h) in enumerate(opt.horizons)
+        h < sigLen && (fc[:, 2k-1:2k] .= NaN)                                       # never assigned upstream (:906-910)
+    end
+    n = opt.signalNrun; nd = n * opt.noiseSamples
+    nsave = length(opt.signalSave)
+    signalvals = Array{Float64}(undef, nd, nsave)
+    signalids = Array{Int64}(undef, nd)
+    for s in 1:opt.noiseSamples
+        r = n*(s-1)+1:n*s
+        signalids[r] .= s                                                            # :903
+        for j in 1:nsave
+            signalvals[r, j] .= sigvals[j, s]                                        # :904
+        end
+    end
+    return (μ = μ, σ = σ, πb = πe, A = A, forecasts = fc, obsdates = fill(enddate(opt), nd),
+            signalvals = signalvals, signalids = signalids)
+end
+
 # ---- CSV output (layout of src/Hmc.jl:707-748) ---------------------------------------------
 function _fmt(x::Float64)
     isnan(x) && return "NaN"
@@ -179,17 +273,42 @@ function _fmt(x::Float64)
                               # (e.g. 24e-11) is reproduced only by the Python host layer so far
 end
 
-function basicsave(data, dates, fname, dataheader; precision=5)
+function basicsave(data, dates, fname, dataheader; precision=5, signal=Array{Float64}(undef, 0, 0), signalids=Int64[])
+    hassig = size(signal, 2) > 0
+    header = vcat(["date"], String.(dataheader))
+    hassig && append!(header, ["signal_$i" for i in 1:size(signal, 2)])
+    !isempty(signalids) && insert!(header, 2, "signalid")                          # :717
     open(fname, "w") do io
-        println(io, join(vcat(["date"], String.(dataheader)), ","))
+        println(io, join(header, ","))
         for i in 1:size(data, 1)
-            println(io, join(vcat([string(dates[i])], [_fmt(round(Float64(v); digits=precision)) for v in data[i, :]]), ","))
+            cells = [string(dates[i])]
+            hassig && push!(cells, string(signalids[i]))                           # only together with signals (:715-717)
+            append!(cells, [_fmt(round(Float64(v); digits=precision)) for v in data[i, :]])
+            hassig && append!(cells, [_fmt(round(Float64(v); digits=5)) for v in signal[i, :]])
+            println(io, join(cells, ","))
         end
     end
 end
 
+function _savesignalresults(samples, opt, dir)
+    h1 = ["state_$i" for i in 1:opt.D]
+    h2 = vec(["trans_$(i)_$(j)" for i in 1:opt.D, j in 1:opt.D])
+    h3 = String[]
+    for h in opt.horizons
+        push!(h3, "forecast_$h"); push!(h3, "forecast_error_$h")
+    end
+    mkpath(dir)
+    kw = (signal = samples.signalvals, signalids = samples.signalids)
+    n = size(samples.μ, 1)
+    basicsave(samples.μ, samples.obsdates, joinpath(dir, "filtered_means_$(enddate(opt)).csv"), h1; kw...)
+    basicsave(samples.σ, samples.obsdates, joinpath(dir, "filtered_variances_$(enddate(opt)).csv"), h1; kw...)
+    basicsave(samples.πb, samples.obsdates, joinpath(dir, "filtered_state_probs_$(enddate(opt)).csv"), h1; kw...)
+    basicsave(reshape(samples.A, n, :), samples.obsdates, joinpath(dir, "filtered_trans_probs_$(enddate(opt)).csv"), h2; kw...)
+    basicsave(samples.forecasts, samples.obsdates, joinpath(dir, "forecasts_$(enddate(opt)).csv"), h3; kw...)
+end
+
 function saveresults(samples, opt, dir; hassignals=false)
-    hassignals && error("signal outputs are outside the accelerated path")
+    hassignals && return _savesignalresults(samples, opt, dir)                     # :735-739 (writes under `dir`)
     h1 = ["state_$i" for i in 1:opt.D]
     h2 = vec(["trans_$(i)_$(j)" for i in 1:opt.D, j in 1:opt.D])
     h3 = String[]
