@@ -93,19 +93,19 @@ int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1);
     HMCG_V(K_, L_, 256, SIG_, SM_, 0, 1, PS_, PB_), HMCG_V(K_, L_, 256, SIG_, SM_, 0, 2, PS_, PB_), \
     HMCG_V(K_, L_, 256, SIG_, SM_, 4, 2, PS_, PB_)
 const Variant g_variants[] = {
-    HMCG_V3(2, 1, false, false, H, P2), HMCG_V3(2, 2, false, false, H, P2), HMCG_V3(2, 4, false, false, H, P2),
+    HMCG_V3(2, 1, false, false, H, P1), HMCG_V3(2, 2, false, false, H, P1), HMCG_V3(2, 4, false, false, H, P2),
     HMCG_V3(2, 8, false, false, H, P2),
     HMCG_V3(3, 1, false, false, P1, P2), HMCG_V3(3, 2, false, false, H, P2), HMCG_V3(3, 4, false, false, H, P2),
     HMCG_V3(3, 8, false, false, H, P2), HMCG_V3(3, 16, false, false, P1, P1),
     HMCG_V(3, 2, 512, false, false, 0, 1, P1, P1), HMCG_V(3, 8, 128, false, false, 0, 1, P1, P1),
-    HMCG_V3(4, 1, false, false, P1, P2), HMCG_V3(4, 2, false, false, H, P2), HMCG_V3(4, 4, false, false, H, P2),
+    HMCG_V3(4, 1, false, false, P1, P2), HMCG_V3(4, 2, false, false, P1, P2), HMCG_V3(4, 4, false, false, H, P2),
     HMCG_V3(4, 8, false, false, H, P2),
     // signal Monte-Carlo path (estimatesignals!): two-population statistics, per-step emission scale
-    HMCG_V3(2, 1, true, false, H, P2), HMCG_V3(2, 2, true, false, H, P2), HMCG_V3(2, 4, true, false, H, P2),
-    HMCG_V3(3, 1, true, false, P1, P2), HMCG_V3(3, 2, true, false, P1, P2), HMCG_V3(3, 4, true, false, H, P2),
+    HMCG_V3(2, 1, true, false, P1, P1), HMCG_V3(2, 2, true, false, H, P1), HMCG_V3(2, 4, true, false, H, P2),
+    HMCG_V3(3, 1, true, false, P1, P1), HMCG_V3(3, 2, true, false, H, P2), HMCG_V3(3, 4, true, false, H, P2),
     HMCG_V3(3, 8, true, false, H, P2),
     // with the smoothed-probability output (full backward pass every sweep)
-    HMCG_V3(2, 1, false, true, H, P2), HMCG_V3(2, 2, false, true, H, P2), HMCG_V3(2, 4, false, true, H, P2),
+    HMCG_V3(2, 1, false, true, P1, P1), HMCG_V3(2, 2, false, true, P1, P2), HMCG_V3(2, 4, false, true, H, P2),
     HMCG_V3(3, 1, false, true, P1, P2), HMCG_V3(3, 2, false, true, H, P2), HMCG_V3(3, 4, false, true, H, P2),
     HMCG_V3(3, 8, false, true, P1, P2),
 };
