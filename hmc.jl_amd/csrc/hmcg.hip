@@ -12,8 +12,7 @@
 #include <mutex>
 #include <vector>
 
-#include "gibbs_device.hpp"
-#include "gibbs_big.hpp"
+#include "variants.hpp"
 
 namespace {
 
@@ -69,58 +68,10 @@ int ensure_context(int device)
     return 0;
 }
 
-using KernelFn = void (*)(const hmcg::KernelParams);
-
-struct Variant {
-    int K, L, NT;
-    KernelFn fn;
-    bool sig, smooth;
-    int NH;                // helper waves on top of the NT window threads (block = NT + 64*NH threads)
-    int occ;               // 2: registers capped so that two plain blocks share a CU
-    int pref_small;        // flavour to run when every window has a CU to itself (W <= CU count)
-    int pref_big;          // flavour for larger batches
-};
-// flavours: P1 = plain, whole register file; P2 = plain, two blocks per CU; H = four helper waves
-enum { P1 = 0, P2 = 1, H = 2 };
+using namespace hmcg_host;
 int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
+const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k4, &g_group_sig, &g_group_smooth };
 
-#define HMCG_V(K_, L_, NT_, SIG_, SM_, NH_, OCC_, PS_, PB_) \
-    { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, SIG_, SM_, NH_, OCC_>, SIG_, SM_, NH_, OCC_, PS_, PB_ }
-// every 256-thread variant in the three flavours, with the one to prefer for small and for large batches
-// (measured: tools/variant_sweep.py, profiles/r01/variant_sweep.txt -- helper waves win while they fit the
-// 256-register cap without spilling, capped plain blocks win once two windows can share a CU)
-#define HMCG_V3(K_, L_, SIG_, SM_, PS_, PB_)                                                   \
-    HMCG_V(K_, L_, 256, SIG_, SM_, 0, 1, PS_, PB_), HMCG_V(K_, L_, 256, SIG_, SM_, 0, 2, PS_, PB_), \
-    HMCG_V(K_, L_, 256, SIG_, SM_, 4, 2, PS_, PB_)
-const Variant g_variants[] = {
-    HMCG_V3(2, 1, false, false, H, P1), HMCG_V3(2, 2, false, false, H, P1), HMCG_V3(2, 4, false, false, H, P2),
-    HMCG_V3(2, 8, false, false, H, P2),
-    HMCG_V3(3, 1, false, false, P1, P2), HMCG_V3(3, 2, false, false, H, P2), HMCG_V3(3, 4, false, false, H, P2),
-    HMCG_V3(3, 8, false, false, H, P2), HMCG_V3(3, 16, false, false, P1, P1),
-    HMCG_V(3, 2, 512, false, false, 0, 1, P1, P1), HMCG_V(3, 8, 128, false, false, 0, 1, P1, P1),
-    HMCG_V3(4, 1, false, false, P1, P2), HMCG_V3(4, 2, false, false, P1, P2), HMCG_V3(4, 4, false, false, H, P2),
-    HMCG_V3(4, 8, false, false, H, P2),
-    // signal Monte-Carlo path (estimatesignals!): two-population statistics, per-step emission scale
-    HMCG_V3(2, 1, true, false, P1, P1), HMCG_V3(2, 2, true, false, H, P1), HMCG_V3(2, 4, true, false, H, P2),
-    HMCG_V3(3, 1, true, false, P1, P1), HMCG_V3(3, 2, true, false, H, P2), HMCG_V3(3, 4, true, false, H, P2),
-    HMCG_V3(3, 8, true, false, H, P2),
-    // with the smoothed-probability output (full backward pass every sweep)
-    HMCG_V3(2, 1, false, true, P1, P1), HMCG_V3(2, 2, false, true, P1, P2), HMCG_V3(2, 4, false, true, H, P2),
-    HMCG_V3(3, 1, false, true, P1, P2), HMCG_V3(3, 2, false, true, H, P2), HMCG_V3(3, 4, false, true, H, P2),
-    HMCG_V3(3, 8, false, true, P1, P2),
-};
-
-using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
-struct BigVariant {
-    int K, NT;
-    BigKernelFn fn;
-};
-const BigVariant g_big_variants[] = {
-    { 2, 256, hmcg::gibbs_sweeps_kernel_big<2, 256> }, { 3, 256, hmcg::gibbs_sweeps_kernel_big<3, 256> },
-    { 4, 256, hmcg::gibbs_sweeps_kernel_big<4, 256> },
-    { 5, 256, hmcg::gibbs_sweeps_kernel_big<5, 256> }, { 6, 256, hmcg::gibbs_sweeps_kernel_big<6, 256> },
-    { 7, 256, hmcg::gibbs_sweeps_kernel_big<7, 256> }, { 8, 256, hmcg::gibbs_sweeps_kernel_big<8, 256> },
-};
 constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
 // The variant for (K, longest window, threads per window, path): the fewest steps per thread that cover the
@@ -129,7 +80,9 @@ const Variant* pick_variant(int K, int maxT, int nt_req, bool sig, bool smooth, 
 {
     const int nt = nt_req > 0 ? nt_req : 256;
     const Variant* best = nullptr;
-    for (const Variant& v : g_variants) {
+    for (const VariantGroup* g : g_groups)
+    for (int i = 0; i < g->n; ++i) {
+        const Variant& v = g->v[i];
         if (v.K != K || v.NT != nt || v.L * v.NT < maxT || v.sig != sig || v.smooth != smooth) continue;
         const int want = force >= 0 ? force : (small_batch ? v.pref_small : v.pref_big);
         const bool better = !best || v.L < best->L ||
@@ -194,7 +147,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     if (const char* fenv = getenv("HMCG_FLAVOUR")) force = !strcmp(fenv, "h") ? H : (!strcmp(fenv, "p2") ? P2 : P1);
     if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
     if (!v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
-        for (const BigVariant& b : g_big_variants) if (b.K == cfg->K) bv = &b;
+        for (int i = 0; i < g_n_big_variants; ++i) if (g_big_variants[i].K == cfg->K) bv = &g_big_variants[i];
         if (bv) {
             bigL = (maxT + bv->NT - 1) / bv->NT;
             dyn = (size_t)bv->NT * bigL * (8 + 8 + 4 + 1) + 16;
