@@ -1,6 +1,6 @@
 """Kernel time of every (K, steps-per-thread, path) variant in its three flavours -- p1 (plain, whole register
 file), p2 (plain, two blocks per CU), h (four helper waves) -- at one window per CU (W = 256) and at eight
-(W = 2048).  Prints one table row per variant; the selection rule in csrc/hmcg.hip is read off this table.
+(W = 2048).  Prints one table row per variant; the preference table in csrc/variants_*.hip is read off this table.
 Usage: python tools/variant_sweep.py [draws]"""
 import ctypes as C
 import os
