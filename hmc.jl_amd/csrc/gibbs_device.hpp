@@ -117,23 +117,22 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return (double)x * 0x1.0p-53;
 }
 
-// exp(x), x <= 0, with a 32-entry table of 2^(j/32) (held in LDS): x = (32 e + j) ln2/32 + r, |r| <= ln2/64,
-// exp(r) by a degree-6 Taylor polynomial (truncation 4e-18), result 2^e * tab[j] * poly: ~1 ulp.
+// exp(x), x <= 0, with a 64-entry table of 2^(j/64) (held in LDS): x = (64 e + j) ln2/64 + r, |r| <= ln2/128,
+// exp(r) by a degree-5 Taylor polynomial (truncation 3.5e-17), result 2^e * tab[j] * poly: ~1 ulp.
 __device__ __forceinline__ double exp_tab(double x, const double* tab)
 {
     x = fmax(x, -746.0);
-    const double n = rint(x * 46.166241308446828);            // 32 / ln 2
-    double r = fma(-n, 2.1660849386535119e-02, x);            // ln2/32 high part (32 significant bits)
-    r = fma(-n, 5.9631716539705866e-12, r);                   // ln2/32 low part
+    const double n = rint(x * 92.332482616893657);            // 64 / ln 2
+    double r = fma(-n, 1.0830424693267560e-02, x);            // ln2/64 high part
+    r = fma(-n, 2.9815858269852933e-12, r);                   // ln2/64 low part
     const int ni = (int)n;
-    const double tj = tab[ni & 31];
-    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
+    const double tj = tab[ni & 63];
+    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
     p = fma(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(tj * p, ni >> 5);
+    return ldexp(tj * p, ni >> 6);
 }
 
 // 1/x: hardware reciprocal + one Newton step (<= 1 ulp; within the parity tolerance)
@@ -576,7 +575,7 @@ struct SweepShared {
     double bred[NW];              // generic block reductions (init)
     double med[2];
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
-    double exptab[32];            // 2^(j/32), j = 0..31
+    double exptab[64];            // 2^(j/64), j = 0..63
     // signal path with signals past the end date: the (scaled) emission values of the last `tail` steps, the
     // filtered probabilities at end_pos, and the current noise sample's last observation (by sample parity)
     double ftail[SIG ? HMCG_MAXTAIL : 1][K];
@@ -683,7 +682,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         return;
     }
 
-    if (tid < 32) sh.exptab[tid] = exp2((double)tid * (1.0 / 32.0));     // correctly rounded enough (OCML exp2, < 1 ulp)
+    if (tid < 64) sh.exptab[tid] = exp2((double)tid * (1.0 / 64.0));     // correctly rounded enough (OCML exp2, < 1 ulp)
     // ---- load the window's observations (once per launch) ----
     double y[L];
     int x[L];
