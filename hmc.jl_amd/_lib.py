@@ -159,10 +159,10 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     yr = None if yreal is None else np.ascontiguousarray(yreal, dtype=np.float64).reshape(W, H)
     out = {}
     nd = max(int(n_samples), 1) * nrun          # kept draws per window (sample-major on the signal path)
-    if want_draws:
-        out["mu"] = np.zeros((W, K, nd)); out["sig2"] = np.zeros((W, K, nd))
-        out["A"] = np.zeros((W, K, K, nd)); out["pi_end"] = np.zeros((W, K, nd))
-        out["fcast"] = np.zeros((W, 2 * H, nd))
+    shapes = dict(mu=(W, K, nd), sig2=(W, K, nd), A=(W, K, K, nd), pi_end=(W, K, nd), fcast=(W, 2 * H, nd))
+    keep = tuple(shapes) if want_draws is True else (tuple(want_draws) if want_draws else ())   # True, False or names
+    for name in keep:
+        out[name] = np.zeros(shapes[name])
     out["summary"] = np.zeros((W, NS))
     out["status"] = np.zeros(W, dtype=np.int32)
     ex = Extras()

@@ -232,6 +232,61 @@ def estimatesignals(opt, device=0):
     return s
 
 
+def estimatesignalswindows(opts, device=0, window_ids=None):
+    """estimatesignals! for many windows in one GPU call (what the reference fans out as one SLURM task per end date,
+    slurmscripts/base_estimation.sh:5): opts is a list of estopt with signal ranges that share D, horizons, the sweep
+    counts, noiseSamples, noise, seed and sigLen.  Windows whose opt.σsignal is 0 get it from a batched base run first
+    (:869-872).  Returns the list of Samples in the order of opts.  RNG stream ids default to the position in `opts`
+    (pass window_ids = zeros to reproduce single-window estimatesignals calls draw for draw)."""
+    o0 = opts[0]
+    W = len(opts)
+    for o in opts:
+        _check_live_path(o)
+        if not len(o.signalRange):
+            raise ValueError("estimatesignalswindows needs a signalRange in every window")
+        same = (o.D, tuple(o.horizons), o.burnin, o.Nrun, o.signalburnin, o.signalNrun, o.noiseSamples, o.noise, o.seed,
+                o.signalRange[-1] - o.endIndex, len(o.signalSave))
+        if same != (o0.D, tuple(o0.horizons), o0.burnin, o0.Nrun, o0.signalburnin, o0.signalNrun, o0.noiseSamples, o0.noise,
+                    o0.seed, o0.signalRange[-1] - o0.endIndex, len(o0.signalSave)):
+            raise ValueError("windows of one call must share D, horizons, sweep counts, noise settings, seed and sigLen")
+    Tw = np.array([len(o.sampleRange) for o in opts], dtype=np.int32)
+    ld = int(Tw.max())
+    Y = np.zeros((W, ld))
+    for w, o in enumerate(opts):
+        Y[w, :Tw[w]] = makey(o)
+    yreal = np.stack([_yreal_row(o.rawdata, o.endIndex, o.horizons) for o in opts])
+    sig = np.array([_sig_ranges(o)[0] for o in opts], dtype=np.int32)
+    sv = np.array([_sig_ranges(o)[1] for o in opts], dtype=np.int32)
+    wid = np.arange(W, dtype=np.uint32) if window_ids is None else np.asarray(window_ids, dtype=np.uint32)
+    need = [w for w, o in enumerate(opts) if o.σsignal == 0]
+    if need:                                               # base runs (:869-872): kappa = 1, alpha = nu = 1, no noise
+        idx = np.array(need)
+        base = _lib.estimate_batch_host(Y[idx], Tw[idx], o0.D, o0.burnin, o0.Nrun, tuple(o0.horizons), yreal[idx], seed=o0.seed,
+                                        device=device, want_draws=("sig2",), window_ids=wid[idx], sig_range=sig[idx],
+                                        save_range=sv[idx], sigma_signal=np.zeros(len(idx)), kappa=1.0, n_samples=1)
+        for i, w in enumerate(need):
+            opts[w].σsignal = float(np.mean(base["sig2"][i].T.copy())) * opts[w].noise     # :871 (summed as estimatesignals does)
+    n, ns = o0.signalNrun, o0.noiseSamples
+    sigLen = o0.signalRange[-1] - o0.endIndex
+    dev_h = [h - sigLen if h > sigLen else 0 for h in o0.horizons]
+    blend = sum(1 << k for k, h in enumerate(o0.horizons) if h == sigLen and sigLen > 0)
+    kw = dict(end_pos=[o.endIndex - 1 for o in opts], blend_mask=blend) if sigLen > 0 else {}
+    res = _lib.estimate_batch_host(Y, Tw, o0.D, o0.signalburnin, n, tuple(dev_h), yreal, seed=o0.seed, device=device,
+                                   window_ids=wid, sig_range=sig, save_range=sv, sigma_signal=[o.σsignal for o in opts],
+                                   kappa=o0.noise, n_samples=ns, alpha=2.0, nu=2.0, **kw)
+    for k, h in enumerate(o0.horizons):
+        if h < sigLen:
+            res["fcast"][:, 2 * k:2 * k + 2] = np.nan
+    out = []
+    nsave = len(o0.signalSave)
+    for w, o in enumerate(opts):
+        s = _unpack(res, w, ns * n, o.D, len(o.horizons), enddate(o))
+        s.signalvals = np.repeat(res["sigvals"][w][:, :nsave], n, axis=0)
+        s.signalids = np.repeat(np.arange(1, ns + 1), n)
+        out.append(s)
+    return out
+
+
 class BatchResult:
     """Result of estimatewindows: per-window posterior summaries (+ optional draws)."""
 

@@ -111,6 +111,35 @@ def test_estimatesignals_like_run_hmm_future_signals(hmclib, oracle, inflation, 
     assert np.max(np.abs(s.signalvals[::25] - o["sigvals"])) < 1e-9
 
 
+def test_estimatesignalswindows_equals_single_window_calls(hmclib, inflation):
+    """The batched signal entry (many end dates in one GPU call) against one estimatesignals call per date, with the
+    single calls' RNG stream id (0) pinned: the same draws, signal values and sigma_signal (set by each base run)."""
+    y, dates = inflation
+    dd = [dt.date.fromisoformat(d) for d in dates]
+
+    def mk(e):
+        return hmc.estopt(y, dd, sampleRange=range(1, e + 2), signalRange=range(e + 1, e + 2), signalSave=range(e + 1, e + 2),
+                          endIndex=e, horizons=[1, 12], D=3, burnin=60, Nrun=90, signalburnin=8, signalNrun=20,
+                          noiseSamples=3, noise=0.5, series="official")
+    ends = [150, 201, 333]
+    single = []
+    for e in ends:
+        o = mk(e)
+        single.append((hmc.estimatesignals(o), o.σsignal))
+    opts = [mk(e) for e in ends]
+    batch = hmc.estimatesignalswindows(opts, window_ids=np.zeros(len(ends)))
+    # (a batch is scanned with the steps-per-thread variant of its longest window, so a shorter window's floats
+    #  can differ from its single-window run in the last bits: 1e-9 like every other GPU comparison, not bitwise)
+    for (s1, ssig), s2, o in zip(single, batch, opts):
+        assert abs(o.σsignal - ssig) < 1e-12 * ssig
+        for k in ("μ", "σ", "πb", "A", "forecasts", "signalvals"):
+            assert np.max(np.abs(getattr(s1, k) - getattr(s2, k))) < 1e-9, k
+        assert list(s1.signalids) == list(s2.signalids) and s1.obsdates == s2.obsdates
+    # default stream ids: window w runs on stream w -- different draws, same posterior region
+    other = hmc.estimatesignalswindows([mk(e) for e in ends])
+    assert np.array_equal(other[0].μ, batch[0].μ) and np.max(np.abs(other[1].μ - batch[1].μ)) > 1e-3
+
+
 @pytest.mark.parametrize("noise", ["0.1", "0.6"])
 def test_gpu_signal_path_vs_reference_dispersion_outputs(hmclib, inflation, noise):
     """The GPU chain against the reference's committed allsignal dispersion outputs (see the oracle test of the
