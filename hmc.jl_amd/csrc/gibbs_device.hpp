@@ -135,7 +135,10 @@ __device__ __forceinline__ double exp_tab(double x, const double* tab)
     return ldexp(tj * p, ni >> 6);
 }
 
-// 1/x: hardware reciprocal + one Newton step (<= 1 ulp; within the parity tolerance)
+// 1/x: hardware reciprocal + one Newton step.  v_rcp_f64 / v_rsq_f64 are 2^-24-grade seeds on gfx950 (measured:
+// tools/ubench/rcp_prec.hip, max relative error 4.5e-8 / 5.2e-8), so one step leaves ~2e-15 relative error -- the
+// source of the ~1e-14 GPU-vs-oracle differences the parity tests observe, five orders inside their 1e-9 tolerance.
+// (sqrt_fast / rsqrt_fast below take two steps and are accurate to the last bit or two.)
 __device__ __forceinline__ double rcp_fast(double x)
 {
     const double r = __builtin_amdgcn_rcp(x);
@@ -358,7 +361,7 @@ __device__ __forceinline__ void rescale_pow2(double (&q)[N])
     for (int i = 0; i < N; ++i) q[i] = ldexp(q[i], e);
 }
 
-// sqrt(x), x > 0 normal: hardware rsq + two Newton steps on the product form (<= 1 ulp)
+// sqrt(x), x > 0 normal: hardware rsq + two Newton steps on the product form (last-bit accurate)
 __device__ __forceinline__ double sqrt_fast(double x)
 {
     double r = __builtin_amdgcn_rsq(x);
@@ -367,7 +370,7 @@ __device__ __forceinline__ double sqrt_fast(double x)
     return fma(fma(-g, g, x), 0.5 * r, g);
 }
 
-// 1/sqrt(x), x > 0 normal: hardware rsq + two Newton steps (<= 1 ulp)
+// 1/sqrt(x), x > 0 normal: hardware rsq + two Newton steps (last-bit accurate)
 __device__ __forceinline__ double rsqrt_fast(double x)
 {
     double r = __builtin_amdgcn_rsq(x);
