@@ -516,7 +516,7 @@ __device__ inline double forecast_value(const double (&mu)[K], const double (&A)
 #pragma unroll
         for (int j = 0; j < K; ++j) M[i][j] = A[i][j];
     }
-    for (unsigned hh = (unsigned)h; hh != 0; hh >>= 1) {        // h is uniform: scalar loop
+    for (unsigned hh = (unsigned)h; hh != 0; hh >>= 1) {        // h differs between horizon lane pairs: per-lane trip count
         if (hh & 1u) {
             double nv[K];
 #pragma unroll
