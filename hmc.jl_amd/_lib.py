@@ -43,7 +43,7 @@ class Extras(C.Structure):
                 ("x_final", C.c_void_p), ("pif_final", C.c_void_p), ("xstate", C.c_void_p), ("sumacc", C.c_void_p), ("window_ids", C.c_void_p),
                 ("sig_range", C.c_void_p), ("save_range", C.c_void_p), ("sigma_signal", C.c_void_p),
                 ("sigvals", C.c_void_p), ("nsave_ld", C.c_int32), ("reserved2", C.c_int32),
-                ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p)]
+                ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p), ("pi_filter_mean", C.c_void_p)]
 
 
 class Timing(C.Structure):
@@ -146,7 +146,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
-                        end_pos=None, blend_mask=0):
+                        end_pos=None, blend_mask=0, want_filter_mean=False):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,)."""
@@ -193,6 +193,9 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     if want_smooth:
         out["pi_smooth_mean"] = np.zeros((W, ldY, K))
         ex.pi_smooth_mean = out["pi_smooth_mean"].ctypes.data
+    if want_filter_mean:
+        out["pi_filter_mean"] = np.zeros((W, ldY, K))
+        ex.pi_filter_mean = out["pi_filter_mean"].ctypes.data
     if want_state:
         out["x_final"] = np.zeros((W, ldY), dtype=np.int32)
         out["pif_final"] = np.zeros((W, ldY, K))

@@ -75,6 +75,8 @@ struct KernelParams {
     // smoothed probabilities (backwardupdate_P!, src/Hmc.jl:442-457): running sum over the kept draws of
     // P(X_t | Y_1:T, theta) in SORTED labels, [W][ldY][K]; divided by nd at the final launch
     double* pi_smooth_mean;
+    // the same running sum for the FILTERED probabilities pif[t,:] (sorted labels), [W][ldY][K]; SMOOTH variants
+    double* pi_filter_mean;
 };
 
 // index of the kept draw produced by global sweep g, or -1 during burn-in
@@ -1214,14 +1216,18 @@ void gibbs_sweeps_kernel(const KernelParams p)
 
     double pf[L][K];     // unsorted filtered probabilities of this thread's steps
     double sm_acc[SMOOTH ? L : 1][K];   // running sums of the smoothed probabilities of this thread's steps
+    double fm_acc[SMOOTH ? L : 1][K];   // ... and of the filtered ones
     if constexpr (SMOOTH) {
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
             for (int q = 0; q < K; ++q)
+            {
                 sm_acc[l][q] = (p.resume && p.pi_smooth_mean && t0 + l < T) ? p.pi_smooth_mean[((size_t)w * p.ldY + t0 + l) * K + q] : 0.0;
+                fm_acc[l][q] = (p.resume && p.pi_filter_mean && t0 + l < T) ? p.pi_filter_mean[((size_t)w * p.ldY + t0 + l) * K + q] : 0.0;
+            }
     }
-    (void)sm_acc;
+    (void)sm_acc; (void)fm_acc;
 #ifdef HMCG_STAMPS
     for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
     stamp_prev = __builtin_amdgcn_s_memtime();
@@ -1670,6 +1676,10 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
                             for (int s = 0; s < K; ++s) gq = (order[q] == s) ? g[s] : gq;
                             sm_acc[l][q] = fma(gq, inv, sm_acc[l][q]);      // sorted labels (:513)
+                            double fq = 0.0;
+#pragma unroll
+                            for (int s = 0; s < K; ++s) fq = (order[q] == s) ? pf[l][s] : fq;
+                            fm_acc[l][q] += fq;                              // sorted pif[t,:] (:512)
                         }
                     }
                     double nb[K];
@@ -1794,6 +1804,14 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t0 + l) * K + s] = pf[l][s];
     }
     if constexpr (SMOOTH) {
+        if (p.pi_filter_mean) {
+            const double sc = (p.final_launch && p.nd > 0) ? 1.0 / (double)p.nd : 1.0;
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if (t0 + l < T)
+#pragma unroll
+                    for (int q = 0; q < K; ++q) p.pi_filter_mean[((size_t)w * p.ldY + t0 + l) * K + q] = fm_acc[l][q] * sc;
+        }
         if (p.pi_smooth_mean) {
             const double sc = (p.final_launch && p.nd > 0) ? 1.0 / (double)p.nd : 1.0;
 #pragma unroll

@@ -136,8 +136,8 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     const BigVariant* bv = nullptr;
     int bigL = 0;
     size_t dyn = 0;
-    const bool use_smooth = ex && ex->pi_smooth_mean != nullptr;
-    if (use_smooth && use_sig) { set_err("pi_smooth_mean is not available on the signal path"); return HMCG_E_UNSUPPORTED; }
+    const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
+    if (use_smooth && use_sig) { set_err("pi_smooth_mean / pi_filter_mean are not available on the signal path"); return HMCG_E_UNSUPPORTED; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).
     // HMCG_FLAVOUR=p1|p2|h and HMCG_HELPERS=0|1 override the table (diagnostics, tools/variant_sweep.py).
@@ -173,7 +173,7 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
     p.resume = resume ? 1 : 0;
     p.final_launch = (p.sweep_end == total_sweeps) ? 1 : 0;
     p.kappa = cfg->kappa;
-    if (ex) p.pi_smooth_mean = ex->pi_smooth_mean;
+    if (ex) { p.pi_smooth_mean = ex->pi_smooth_mean; p.pi_filter_mean = ex->pi_filter_mean; }
     if (ex) { p.sig_range = ex->sig_range; p.save_range = ex->save_range; p.sigma_signal = ex->sigma_signal; p.sigvals = ex->sigvals; p.nsave_ld = ex->nsave_ld; }
     if (use_sig) { p.end_pos = ex->end_pos; p.blend_mask = cfg->blend_mask; }
     for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
@@ -319,7 +319,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     DevBuf<uint8_t> dxs;
     DevBuf<uint32_t> dwid;
     DevBuf<int32_t> dsr, dsv, dep;
-    DevBuf<double> dss, dsvals, dsm;
+    DevBuf<double> dss, dsvals, dsm, dfm;
 #define ALLOC(buf, n) do { if ((buf).alloc(n) != 0) { set_err("hipMalloc of %zu elements failed", (size_t)(n)); return HMCG_E_NOMEM; } } while (0)
     ALLOC(dY, W * ld); ALLOC(dT, W); ALLOC(dst, W);
     HIP_TRY(hipMemcpyAsync(dY.p, Y, sizeof(double) * W * ld, hipMemcpyHostToDevice, s));
@@ -363,6 +363,12 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
             else HIP_TRY(hipMemsetAsync(dsm.p, 0, sizeof(double) * W * ld * K, s));
             dex.pi_smooth_mean = dsm.p;
         }
+        if (extras->pi_filter_mean) {
+            ALLOC(dfm, W * ld * K);
+            if (resume) HIP_TRY(hipMemcpyAsync(dfm.p, extras->pi_filter_mean, sizeof(double) * W * ld * K, hipMemcpyHostToDevice, s));
+            else HIP_TRY(hipMemsetAsync(dfm.p, 0, sizeof(double) * W * ld * K, s));
+            dex.pi_filter_mean = dfm.p;
+        }
         if (extras->window_ids) { ALLOC(dwid, W); HIP_TRY(hipMemcpyAsync(dwid.p, extras->window_ids, sizeof(uint32_t) * W, hipMemcpyHostToDevice, s)); dex.window_ids = dwid.p; }
         if (extras->sumacc) {
             ALLOC(dacc, W * (NS + K));
@@ -386,6 +392,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     if (extras) {
         D2H(extras->sigvals, dsvals.p, sizeof(double) * W * nsmp * (size_t)(extras->nsave_ld > 0 ? extras->nsave_ld : 0));
         D2H(extras->pi_smooth_mean, dsm.p, sizeof(double) * W * ld * K);
+        D2H(extras->pi_filter_mean, dfm.p, sizeof(double) * W * ld * K);
         D2H(extras->x_final, dxf.p, sizeof(int32_t) * W * ld);
         D2H(extras->pif_final, dpif.p, sizeof(double) * W * ld * K);
         D2H(extras->xstate, dxs.p, W * ld);

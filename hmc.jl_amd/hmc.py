@@ -174,10 +174,11 @@ def estimatemodel(opt, device=0, smooth=False):
         kw = dict(sig_range=[sig], save_range=[sv], sigma_signal=[0.0], kappa=1.0, n_samples=1)
     res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.burnin, opt.Nrun, tuple(opt.horizons),
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
-                                   device=device, want_smooth=smooth, **kw)
+                                   device=device, want_smooth=smooth, want_filter_mean=smooth, **kw)
     s = _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
     if smooth:
         s.πb_mean = res["pi_smooth_mean"][0, :len(Y)]
+        s.πf_mean = res["pi_filter_mean"][0, :len(Y)]      # draw-averaged filtered probabilities (sorted labels)
     return s
 
 

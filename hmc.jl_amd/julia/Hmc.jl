@@ -70,6 +70,7 @@ struct hmcg_extras
     reserved2::Int32
     end_pos::Ptr{Int32}
     pi_smooth_mean::Ptr{Float64}
+    pi_filter_mean::Ptr{Float64}
 end
 const HMCG_MAXTAIL = 32
 
@@ -218,7 +219,7 @@ function _signal_call(opt::estopt, burnin, nrun, n_samples, σsignal, κ, α, ν
     rc = GC.@preserve Y T yreal μ σ A πe fc st sig sv ssig sigvals ep begin
         ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
                              pointer(sig), pointer(sv), pointer(ssig), pointer(sigvals), Int32(max(nsave, 1)), Int32(0),
-                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL))
+                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL, C_NULL))
         ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
               (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{hmcg_extras}, Ptr{Cvoid}),

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 101
+#define HMCG_VERSION 102
 #define HMCG_MAXH 8
 #define HMCG_MAXTAIL 32         /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
@@ -136,6 +136,10 @@ typedef struct hmcg_extras {
                                    P(X_t | Y_1:T, theta) in sorted labels = the draw-average of the reference's
                                    samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  K <= 3 variants;
                                    costs about 20 % more per sweep.  NULL: only pib[end,:] is produced */
+    double* pi_filter_mean;     /* [W][ldY][K] optional: the same draw average for the FILTERED probabilities pif[t,:] in
+                                   sorted labels (what the reference's older API returned as "pib" and averaged per date in
+                                   data/output/official_insample/forecats_insample.csv, columns s1..s3).  Runs on the same
+                                   kernel variants as pi_smooth_mean */
 } hmcg_extras;
 
 typedef struct hmcg_timing {

@@ -542,9 +542,11 @@ int hmco_estimate_window_ex(const double *Y, int T, int K, int burnin, int nrun,
                             int end_pos, int blend_mask,
                             double *mu, double *sig2, double *A, double *pi_end, double *fcast,
                             double *pi_smooth, double *summary, double *sigvals,
-                            int *x_final, double *pif_final, int *status)
+                            int *x_final, double *pif_final, double *pi_filter_mean, int *status)
 {
-    /* end_pos: 0-based position whose SMOOTHED state probabilities are reported as pi_end -- the reference's
+    /* pi_filter_mean [T][K]: mean over the kept draws of the label-sorted FILTERED probabilities pif[t,:] (:512) --
+     * what data/output/official_insample/forecats_insample.csv holds in s1..s3 (an older API's "pib").
+     * end_pos: 0-based position whose SMOOTHED state probabilities are reported as pi_end -- the reference's
      * samples.pib[:, opt.endIndex, :] (:900) when the window carries sigLen = T-1-end_pos signal steps past the
      * end date (:888); negative or T-1 = the last step (smoothed == filtered there).
      * blend_mask bit k: horizon k equals sigLen and is reported through forecastsignal (:670-681, :908-909)
@@ -573,6 +575,7 @@ int hmco_estimate_window_ex(const double *Y, int T, int K, int burnin, int nrun,
     c.alpha = alpha; c.nu = nu;
     const int NS = 3 * K + K * K + 2 * H;
     const int nd = n_samples * nrun;
+    if (pi_filter_mean) for (int i = 0; i < T * K; ++i) pi_filter_mean[i] = 0.0;
     double acc[3 * HMCO_MAXK + HMCO_MAXK * HMCO_MAXK + 2 * HMCO_MAXH];
     for (int i = 0; i < NS; ++i) acc[i] = 0.0;
     int order[HMCO_MAXK];
@@ -622,9 +625,13 @@ int hmco_estimate_window_ex(const double *Y, int T, int K, int burnin, int nrun,
             if (pi_smooth)
                 for (int k = 0; k < K; ++k) for (int t = 0; t < T; ++t)
                     pi_smooth[((size_t)k * T + t) * nd + d] = PIB(&c, t, order[k]);
+            if (pi_filter_mean)
+                for (int t = 0; t < T; ++t) for (int k = 0; k < K; ++k)
+                    pi_filter_mean[(size_t)t * K + k] += PIF(&c, t, order[k]);
         }
     }
     if (summary) for (int i = 0; i < NS; ++i) summary[i] = nd > 0 ? acc[i] / nd : NAN;
+    if (pi_filter_mean && nd > 0) for (int i = 0; i < T * K; ++i) pi_filter_mean[i] /= nd;
     if (x_final) for (int t = 0; t < T; ++t) x_final[t] = c.X[t];
     if (pif_final) memcpy(pif_final, c.pif, sizeof(double) * (size_t)T * K);
     if (status) *status = c.status;
@@ -641,7 +648,7 @@ int hmco_estimate_window(const double *Y, int T, int K, int burnin, int nrun,
 {
     return hmco_estimate_window_ex(Y, T, K, burnin, nrun, horizons, H, yreal, seed, window_id, flags, x_init,
                                    T, T, 1.0, 1.0, 1.0, 1, 0.0, 0, 0, -1, 0,
-                                   mu, sig2, A, pi_end, fcast, pi_smooth, summary, NULL, x_final, pif_final, status);
+                                   mu, sig2, A, pi_end, fcast, pi_smooth, summary, NULL, x_final, pif_final, NULL, status);
 }
 
 /* Batched form over W windows (window-major Y panel, ld = ldY), one window per

@@ -193,6 +193,29 @@ def test_smoothed_probabilities_mean(hmclib, oracle, K, lens):
         assert close(g["mu"][w].T, o["mu"]) < TOL
 
 
+def test_filtered_probability_mean_and_reference_insample_fixture(hmclib, oracle, inflation):
+    """extras.pi_filter_mean: the draw average of the label-sorted filtered probabilities.  (1) against the oracle's
+    running mean: 1e-9; flavours bit-identical.  (2) at the scale of the reference's committed
+    official_insample/forecats_insample.csv (20k + 10k sweeps on 1970-01..2017-12, K = 3): its s1..s3 columns, which
+    are these probabilities (see the oracle test of the same name for the tolerances)."""
+    import csv
+    import os
+    y, dates = inflation
+    Y = y[None, :576]
+    Tw = np.array([576], dtype=np.int32)
+    g = _lib.estimate_batch_host(Y, Tw, 3, 30, 60, (12,), np.array([[y[587]]]), want_filter_mean=True, want_smooth=True)
+    o = oracle.estimate_signals(y[:576], 3, 30, 60, 1, horizons=(12,), yreal=[y[587]], want_filter_mean=True)
+    assert close(g["pi_filter_mean"][0], o["pi_filter_mean"]) < TOL
+    only = _lib.estimate_batch_host(Y, Tw, 3, 30, 60, (12,), np.array([[y[587]]]), want_filter_mean=True)    # without the smoother output
+    assert np.array_equal(only["pi_filter_mean"], g["pi_filter_mean"]) and np.array_equal(only["mu"], g["mu"])
+    rows = list(csv.DictReader(open(os.path.join(os.path.dirname(__file__), "golden", "official_insample_forecats_insample.csv"))))
+    s = np.array([[float(r["s1"]), float(r["s2"]), float(r["s3"])] for r in rows])
+    big = _lib.estimate_batch_host(Y, Tw, 3, 20000, 10000, (12,), np.array([[y[587]]]), want_draws=False, want_filter_mean=True)
+    d = np.abs(big["pi_filter_mean"][0] - s)
+    assert d.mean() < 0.02 and d.max() < 0.3
+    assert min(np.corrcoef(big["pi_filter_mean"][0][:, k], s[:, k])[0, 1] for k in range(3)) > 0.99
+
+
 def test_mixed_lengths_in_one_call(hmclib, oracle):
     lens = [1000, 17, 400, 2]
     Y, Tw, fut = synth.generate_panel(4, 1000, 3, ragged=lens)
@@ -313,7 +336,7 @@ def test_kernel_flavours_are_bit_identical(hmclib, monkeypatch, K):
         extra = [dict()]
         if K <= 3 and ld <= 1024:
             sig = np.stack([np.maximum(Tw[idx] - 12, 0), Tw[idx]], axis=1).astype(np.int32)
-            extra += [dict(sig_range=sig, kappa=1.0, n_samples=2, sigma_signal=np.full(len(idx), 0.3)), dict(want_smooth=True)]
+            extra += [dict(sig_range=sig, kappa=1.0, n_samples=2, sigma_signal=np.full(len(idx), 0.3)), dict(want_smooth=True, want_filter_mean=True)]
         for kw in extra:
             res = {}
             for fl in ("p1", "p2", "h"):       # plain / plain capped for two blocks per CU / helper waves
@@ -326,6 +349,7 @@ def test_kernel_flavours_are_bit_identical(hmclib, monkeypatch, K):
                     assert np.array_equal(a[k], b[k], equal_nan=True), (K, sub, sorted(kw), fl, k)
                 if "want_smooth" in kw:
                     assert np.array_equal(a["pi_smooth_mean"], b["pi_smooth_mean"])
+                    assert np.array_equal(a["pi_filter_mean"], b["pi_filter_mean"])
 
 
 def test_batch_larger_than_the_gpu_matches_small_batches(hmclib):

@@ -6,10 +6,14 @@ data/output/official/*_summary.csv (100k burn-in + 250k draws upstream; here 3k 
 draws, tolerances = the reference's MC noise at this length) and the
 truth-recovery tolerances of test/runtests.jl:56-57.
 """
+import os
+
 import numpy as np
 import pytest
 
 from hmc_jl_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 DATES = {120: "1979-12-01", 350: "1999-02-01", 579: "2018-03-01"}
 
@@ -146,3 +150,26 @@ def test_signal_model_two_population_update(oracle):
         assert abs(v[i] - e_sig) < 5 * e_sig / np.sqrt(a - 2.0) / np.sqrt(400), (i, v[i], e_sig)
         e_mu = (yo.sum() + ys.sum() + 2.0 * xi) / (Neff + 2.0)
         assert abs(m[i] - e_mu) < 5 * np.sqrt(e_sig / (Neff + 2.0)) / np.sqrt(400), (i, m[i], e_mu)
+
+
+def test_oracle_filtered_probabilities_vs_reference_insample_fixture(oracle, inflation):
+    """data/output/official_insample/forecats_insample.csv (code/run_insamplefcasts.jl: one window 1970-01..2017-12,
+    K = 3, 20k + 10k sweeps) holds per date the mean over draws of what that older API called samples.pib[:, date, :].
+    Those columns (s1..s3) are the draw-averaged label-sorted FILTERED probabilities -- they lag the smoothed ones at
+    every regime change -- so they pin pif[t,:] at all 576 interior dates (the summaries only pin the last date of
+    each window).  The fixture predates the current module (different API, 5-sigma differences at ambiguous
+    observations near y = 5), hence tolerances well above the Monte-Carlo error (0.002 mean, 0.035 max)."""
+    import csv
+    y, dates = inflation
+    rows = list(csv.DictReader(open(os.path.join(GOLDEN, "official_insample_forecats_insample.csv"))))
+    assert len(rows) == 576 and rows[0]["date"] == dates[0] and rows[-1]["date"] == dates[575]
+    assert np.array_equal(np.array([float(r["current"]) for r in rows]), y[:576])        # the same float32-widened series
+    s = np.array([[float(r["s1"]), float(r["s2"]), float(r["s3"])] for r in rows])
+    o = oracle.estimate_signals(y[:576], 3, 1500, 2500, 1, horizons=(12,), yreal=[y[587]], want_filter_mean=True)
+    f = o["pi_filter_mean"]
+    assert np.max(np.abs(f.sum(axis=1) - 1)) < 1e-12
+    d = np.abs(f - s)
+    assert d.mean() < 0.02 and d.max() < 0.3
+    assert min(np.corrcoef(f[:, k], s[:, k])[0, 1] for k in range(3)) > 0.99
+    sm = oracle.estimate_window(y[:576], 3, 1500, 2500, (12,), [y[587]], want_smooth=True)["pi_smooth"].mean(axis=0)
+    assert np.abs(sm - s).mean() > 3 * d.mean()                                          # not the smoothed probabilities
