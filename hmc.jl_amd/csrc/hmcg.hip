@@ -131,12 +131,13 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
         return HMCG_E_BADARG;
     }
     if (cfg->blend_mask < 0 || (cfg->H < 31 && (cfg->blend_mask >> cfg->H) != 0)) { set_err("blend_mask has bits beyond H"); return HMCG_E_BADARG; }
-    if (use_sig && cfg->K >= 5) { set_err("signal path: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
+    const bool use_smooth_req = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
+    if ((use_sig || use_smooth_req) && cfg->K >= 5) { set_err("signal path and smoothed / filtered means: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     const Variant* v = nullptr;
     const BigVariant* bv = nullptr;
     int bigL = 0;
     size_t dyn = 0;
-    const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
+    const bool use_smooth = use_smooth_req;
     if (use_smooth && use_sig) { set_err("pi_smooth_mean / pi_filter_mean are not available on the signal path"); return HMCG_E_UNSUPPORTED; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).

@@ -134,7 +134,7 @@ typedef struct hmcg_extras {
                                    horizons[k] = h - sigLen, or set blend_mask for h == sigLen */
     double* pi_smooth_mean;     /* [W][ldY][K] optional: mean over the kept draws of the SMOOTHED probabilities
                                    P(X_t | Y_1:T, theta) in sorted labels = the draw-average of the reference's
-                                   samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  K <= 3 variants;
+                                   samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  K <= 4 variants;
                                    costs about 20 % more per sweep.  NULL: only pib[end,:] is produced */
     double* pi_filter_mean;     /* [W][ldY][K] optional: the same draw average for the FILTERED probabilities pif[t,:] in
                                    sorted labels (what the reference's older API returned as "pib" and averaged per date in

@@ -129,7 +129,7 @@ def test_signal_path_all_signal_real_data(hmclib, oracle, inflation):
 
 def test_signal_path_partial_signal_synthetic(hmclib, oracle):
     """Signals on the tail of the window only (two populations in the conjugate update), K = 2 and 3, L = 1..4."""
-    for K, T in ((3, 1000), (2, 300), (3, 500)):
+    for K, T in ((3, 1000), (2, 300), (3, 500), (4, 600)):
         Y, Tw, fut = synth.generate_panel(3, T, K)
         sig = np.array([[T - 40, T], [T - 1, T], [T // 2, T]]); save = np.array([[T - 3, T], [T - 1, T], [T - 2, T]])
         check_signals_against_oracle(oracle, Y, Tw, K, 3, 8, 3, sig, save, 0.6, 2.0, 2.0, np.array([0.5, 1.0, 0.2]), fut[:, 11:12])
@@ -175,7 +175,7 @@ def test_signal_path_signals_past_the_end_date(hmclib, oracle, K, T, sigLen):
     assert (bad["status"] == _lib.ST_BAD_T).all()
 
 
-@pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64, 5]), (2, [300, 2, 129])])
+@pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64, 5]), (2, [300, 2, 129]), (4, [700, 100, 3])])
 def test_smoothed_probabilities_mean(hmclib, oracle, K, lens):
     """Optional output: the draw-average of the smoothed probabilities pib[:, t, :] (backwardupdate_P!,
     src/Hmc.jl:442-457, sorted labels :513).  The GPU runs the beta recursion as a suffix scan; the oracle
@@ -334,7 +334,7 @@ def test_kernel_flavours_are_bit_identical(hmclib, monkeypatch, K):
         args = (np.ascontiguousarray(Y[idx, :ld]), Tw[idx], K, 3, 12, (3, 12, 40),
                 np.column_stack([fut[idx, 2], fut[idx, 11], np.zeros(len(idx))]))      # h=40 takes the long-horizon branch
         extra = [dict()]
-        if K <= 3 and ld <= 1024:
+        if ld <= 1024:
             sig = np.stack([np.maximum(Tw[idx] - 12, 0), Tw[idx]], axis=1).astype(np.int32)
             extra += [dict(sig_range=sig, kappa=1.0, n_samples=2, sigma_signal=np.full(len(idx), 0.3)), dict(want_smooth=True, want_filter_mean=True)]
         for kw in extra:

@@ -52,10 +52,10 @@ def time_one(K, T, W, path, flavour, n):
 
 
 rows = []
-for path, Ks in (("base", (2, 3, 4)), ("sig", (2, 3)), ("smooth", (2, 3))):
+for path, Ks in (("base", (2, 3, 4)), ("sig", (2, 3, 4)), ("smooth", (2, 3, 4))):
     for K in Ks:
         for L in (1, 2, 4, 8, 16):
-            if (L == 16 and not (K == 3 and path == "base")) or (L == 8 and K == 2 and path != "base"):
+            if (L == 16 and not (K == 3 and path == "base")) or (L == 8 and K != 3 and path != "base"):
                 continue
             T = 256 * L - 24
             line = "%-6s K=%d L=%-2d T=%-4d" % (path, K, L, T)
