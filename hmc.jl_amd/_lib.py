@@ -18,7 +18,8 @@ HMCG_MAXH = 8
 HMCG_MAXK = 8
 FLAG_RESUME = 1
 
-ST_BAD_INVGAMMA, ST_EMIS_UNDERFLOW, ST_NONFINITE, ST_GAMMA_CAP, ST_BAD_T = 1, 2, 4, 8, 16
+ST_BAD_INVGAMMA, ST_EMIS_UNDERFLOW, ST_NONFINITE, ST_GAMMA_CAP, ST_BAD_T, ST_BAD_RANGE = 1, 2, 4, 8, 16, 32
+ST_SKIPPED = ST_NONFINITE | ST_BAD_T | ST_BAD_RANGE      # the window was not computed at all
 
 HMCG_MAXTAIL = 32
 EXPORTS = ("hmcg_version", "hmcg_device_count", "hmcg_last_error", "hmcg_shutdown",
@@ -220,6 +221,13 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                                _np_ptr(out.get("pi_end")), _np_ptr(out.get("fcast")), _np_ptr(out["summary"]),
                                _np_ptr(out["status"]), C.byref(ex), C.byref(tm))
     _check(rc)
+    # a skipped window (non-finite data, bad T, bad ranges) was not computed: its outputs read NaN, never a
+    # plausible-looking zero (the reference would have thrown, src/Hmc.jl:435)
+    skipped = (out["status"] & ST_SKIPPED) != 0
+    if skipped.any():
+        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final"):
+            if name in out:
+                out[name][skipped] = np.nan
     out["kernel_ms"] = tm.kernel_ms
     out["threads_per_window"] = tm.threads_per_window
     out["steps_per_thread"] = tm.steps_per_thread

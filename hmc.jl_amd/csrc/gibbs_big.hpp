@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     constexpr int NSH = NW - 1;
 
     // ---- shadow jobs -------------------------------------------------------------------------
-    auto job_prep = [&](int sw) {                    // see gibbs_device.hpp job_prep
+    auto job_prep = [&](int sw) __attribute__((always_inline)) {                    // see gibbs_device.hpp job_prep
         Rng g = rng;
         g.sweep = (uint32_t)sw;
         RngBuf<K>& rb = sh.rb[sw & 1];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
         }
     };
-    auto job_uniforms = [&](int sw, int b0, int b1) {
+    auto job_uniforms = [&](int sw, int b0, int b1) __attribute__((always_inline)) {
         Rng g = rng;
         g.sweep = (uint32_t)sw;
         for (int b = b0 + lane; b < b1; b += 128) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         }
         if (fc_e >= 0) sum_fc = p.sumacc[(size_t)w * NCK + NP + fc_e];
     }
-    auto job_outputs = [&](int sw) {
+    auto job_outputs = [&](int sw) __attribute__((always_inline)) {
         const int d = sw >= p.burnin_s ? sw - p.burnin_s : -1;       // one sample per launch on this path
         if (d < 0) return;
         const ThetaBufBig<K>& th = sh.th[sw & 1];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     };
 
     // ---- sufficient statistics of the chain state in xs[] -------------------------------------
-    auto publish_stats = [&]() {
+    auto publish_stats = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < KK; e += 64) sh.cnt[wave][e] = 0;
         __builtin_amdgcn_wave_barrier();
         double d1[K], d2[K];

@@ -119,22 +119,36 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return (double)x * 0x1.0p-53;
 }
 
-// exp(x), x <= 0, with a 64-entry table of 2^(j/64) (held in LDS): x = (64 e + j) ln2/64 + r, |r| <= ln2/128,
-// exp(r) by a degree-5 Taylor polynomial (truncation 3.5e-17), result 2^e * tab[j] * poly: ~1 ulp.
+// exp(x), x <= 0, with a table of 2^(j/N) held in LDS: x = (N e + j) ln2/N + r, |r| <= ln2/(2N), exp(r) by a
+// Taylor polynomial, result 2^e * tab[j] * poly: ~1 ulp.  N = 64 with degree 5 (truncation 3.5e-17) or N = 256 with
+// degree 4 (3.8e-17).
+#ifndef HMCG_EXPTAB_N
+#define HMCG_EXPTAB_N 64
+#endif
+constexpr int EXPTAB_N = HMCG_EXPTAB_N;
+static_assert(EXPTAB_N == 64 || EXPTAB_N == 256, "exp table: 64 or 256 entries");
 __device__ __forceinline__ double exp_tab(double x, const double* tab)
 {
     x = fmax(x, -746.0);
-    const double n = rint(x * 92.332482616893657);            // 64 / ln 2
-    double r = fma(-n, 1.0830424693267560e-02, x);            // ln2/64 high part
-    r = fma(-n, 2.9815858269852933e-12, r);                   // ln2/64 low part
+    double n, r, p;
+    if constexpr (EXPTAB_N == 64) {
+        n = rint(x * 92.332482616893657);                     // 64 / ln 2
+        r = fma(-n, 1.0830424693267560e-02, x);               // ln2/64 high part
+        r = fma(-n, 2.9815858269852933e-12, r);               // ln2/64 low part
+        p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+        p = fma(p, r, 1.0 / 6.0);
+    } else {
+        n = rint(x * 369.3299304675746);                      // 256 / ln 2
+        r = fma(-n, 2.70760617331689e-03, x);                 // ln2/256 high part
+        r = fma(-n, 7.453964567463233e-13, r);                // ln2/256 low part
+        p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    }
     const int ni = (int)n;
-    const double tj = tab[ni & 63];
-    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    const double tj = tab[ni & (EXPTAB_N - 1)];
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(tj * p, ni >> 6);
+    return ldexp(tj * p, ni >> (EXPTAB_N == 64 ? 6 : 8));
 }
 
 // 1/x: hardware reciprocal + one Newton step.  v_rcp_f64 / v_rsq_f64 are 2^-24-grade seeds on gfx950 (measured:
@@ -580,7 +594,7 @@ struct SweepShared {
     double bred[NW];              // generic block reductions (init)
     double med[2];
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
-    double exptab[64];            // 2^(j/64), j = 0..63
+    double exptab[EXPTAB_N];      // 2^(j/N), j = 0..N-1
     // signal path with signals past the end date: the (scaled) emission values of the last `tail` steps, the
     // filtered probabilities at end_pos, and the current noise sample's last observation (by sample parity)
     double ftail[SIG ? HMCG_MAXTAIL : 1][K];
@@ -687,7 +701,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         return;
     }
 
-    if (tid < 64) sh.exptab[tid] = exp2((double)tid * (1.0 / 64.0));     // correctly rounded enough (OCML exp2, < 1 ulp)
+    if (tid < EXPTAB_N) sh.exptab[tid] = exp2((double)tid * (1.0 / EXPTAB_N));     // correctly rounded enough (OCML exp2, < 1 ulp)
     // ---- load the window's observations (once per launch) ----
     double y[L];
     int x[L];
@@ -710,6 +724,16 @@ void gibbs_sweeps_kernel(const KernelParams p)
     const double kfac = SIG ? 1.0 / (1.0 + p.kappa) : 1.0;
     if constexpr (SIG) {
         if (p.sig_range) { sb = p.sig_range[2 * w]; se = p.sig_range[2 * w + 1]; }
+        // caller data: ranges must lie inside the window and the saved range must fit its slab (uniform per block)
+        bool bad_range = sb < 0 || se > T || (sb < se && se != T);
+        if (p.save_range) {
+            const int svb = p.save_range[2 * w], sve = p.save_range[2 * w + 1];
+            bad_range |= svb < 0 || sve > T || (svb < sve && p.sigvals && sve - svb > p.nsave_ld);
+        }
+        if (bad_range) {
+            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_RANGE);
+            return;
+        }
         if (sb >= se) { sb = T; se = T; }
 #pragma unroll
         for (int l = 0; l < L; ++l) yreal[l] = y[l];
@@ -828,7 +852,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     //   [K+2NG, 2K+2NG)       normal for mu_i                                  (site 1)
     //   [2K+2NG, 2K+4NG)      log(1-u) of gamma role, attempt                  (block index 2j+1)
     // Every task is one Philox block and one log; the normals add sqrt*cos.
-    auto job_prep = [&](int sw) {
+    auto job_prep = [&](int sw) __attribute__((always_inline)) {
         Rng g = rng;
         g.sweep = (uint32_t)sw;
         RngBuf<K>& rb = sh.rb[sw & 1];
@@ -870,7 +894,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     static_assert(NW > 2 || 3 * K + KK <= 64 - 2 * HMCG_MAXH, "parameter and forecast output lanes share a wave when NW == 2");
     // uniforms for the state draws of sweep `sw` (site 4, index t): block b covers t = 2b, 2b+1.
     // Blocks [b0, b1) are dealt round-robin to the calling wave's lanes.
-    auto job_uniforms = [&](int sw, int b0, int b1) {
+    auto job_uniforms = [&](int sw, int b0, int b1) __attribute__((always_inline)) {
         Rng g = rng;
         g.sweep = (uint32_t)sw;
         for (int b = b0 + lane; b < b1; b += 128) {       // two independent blocks per trip (ILP across the mul chains)
@@ -922,7 +946,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         }
     }
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
-    auto job_outputs = [&](int sw) {
+    auto job_outputs = [&](int sw) __attribute__((always_inline)) {
         // (without the signal path a launch is one sample: no division needed to find the kept-draw index)
         const int d = SIG ? kept_index(p, sw) : (sw >= p.burnin_s ? sw - p.burnin_s : -1);
         if (d < 0 || orole < 0) return;
@@ -1045,7 +1069,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     constexpr int NWORD = (NF + FPW - 1) / FPW;
     constexpr int NPK = Sh::NPK;
     static_assert(64 * L < 65536, "16-bit wave totals");
-    auto publish_stats = [&]() {
+    auto publish_stats = [&]() __attribute__((always_inline)) {
         // ---- transition counts C_ij: per-thread PB-bit fields -> 16-bit fields -> one DPP integer sum per word
         unsigned acc[NWORD];
 #pragma unroll
@@ -1161,7 +1185,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     };
     // a new noise sample (src/Hmc.jl:892): Yfake = Yreal + N(0,1) * sigma_signal on the signal range; the chain
     // state carries over (:889-895) and the statistics are retaken on the new data
-    auto regen_y = [&](int smp, bool report) {
+    auto regen_y = [&](int smp, bool report) __attribute__((always_inline)) {
         if constexpr (SIG) {
             const double ssig = p.sigma_signal ? p.sigma_signal[w] : 0.0;
             const bool noisy = ssig != 0.0 || p.n_samples > 1;
@@ -1177,7 +1201,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     gn.block(SITE_NOISE, 0, (uint32_t)t, r);
                     y[l] = yreal[l] + box_muller(r) * ssig;
                 }
-                if (report && p.sigvals && t >= svb && t < sve && t < T)
+                if (report && p.sigvals && t >= svb && t < sve && t < T && (t - svb) < p.nsave_ld)
                     p.sigvals[((size_t)w * p.n_samples + smp) * p.nsave_ld + (t - svb)] = y[l];
                 if (t == T - 1) sh.y_last[smp & 1] = y[l];       // forecastsignal's `signal` (:909)
             }
@@ -1206,7 +1230,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         }
         trips = __builtin_amdgcn_readfirstlane(trips);
     }
-    auto job_uniform_trips = [&](int sw) {
+    auto job_uniform_trips = [&](int sw) __attribute__((always_inline)) {
         const int nblk = (T + 1) >> 1;
         for (uint32_t m = trips; m != 0; m &= m - 1) {
             const int k = __builtin_ctz(m);

@@ -143,6 +143,30 @@ def _sig_ranges(opt):
     return sig, sv
 
 
+def _check_status(status, what):
+    """Per-window status words of a finished call: a window the library skipped is an error here, as it is upstream
+    (a NaN observation or an empty window makes the reference throw, src/Hmc.jl:435,464); the numerical flags only warn."""
+    import warnings
+    status = np.atleast_1d(np.asarray(status))
+    bad = np.nonzero(status & _lib.ST_SKIPPED)[0]
+    if len(bad):
+        names = {_lib.ST_NONFINITE: "non-finite observation", _lib.ST_BAD_T: "window length / end position out of range",
+                 _lib.ST_BAD_RANGE: "signal or save range out of range"}
+        why = sorted({n for w in bad for b, n in names.items() if status[w] & b})
+        raise _lib.HmcgError("%s: window(s) %s were not estimated (%s); their outputs are NaN"
+                             % (what, ", ".join(str(int(w)) for w in bad[:8]), "; ".join(why)))
+    other = np.nonzero(status)[0]
+    if len(other):
+        warnings.warn("%s: numerical flags raised in %d window(s) (status bits %s): see HMCG_ST_* in include/hmcg.h"
+                      % (what, len(other), sorted({int(s) for s in status[other]})), RuntimeWarning, stacklevel=3)
+
+
+# RNG stream of estimatesignals!' base run (:869-872): window id with the top bit set, so that the base chain and the
+# first noise sample -- same seed, same window, same sweep numbers -- do not replay the same Philox counters
+# (upstream's single MersenneTwister stream simply continues from one run into the next)
+BASE_RUN_STREAM = 0x80000000
+
+
 def _unpack(res, w, nrun, K, H, obsdate):
     mu = res["mu"][w].T.copy()                       # (nrun, K)
     sig = res["sig2"][w].T.copy()
@@ -152,7 +176,7 @@ def _unpack(res, w, nrun, K, H, obsdate):
     return Samples(mu, sig, pe[:, None, :], A, fc, [obsdate] * nrun, int(res["status"][w]))
 
 
-def estimatemodel(opt, device=0, smooth=False):
+def estimatemodel(opt, device=0, smooth=False, window_id=0):
     """Hmc.estimatemodel(opt) (src/Hmc.jl:850-865) on the GPU.
 
     smooth=True additionally runs the full backward pass (backwardupdate_P!, :442-457) every sweep and
@@ -174,7 +198,8 @@ def estimatemodel(opt, device=0, smooth=False):
         kw = dict(sig_range=[sig], save_range=[sv], sigma_signal=[0.0], kappa=1.0, n_samples=1)
     res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.burnin, opt.Nrun, tuple(opt.horizons),
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
-                                   device=device, want_smooth=smooth, want_filter_mean=smooth, **kw)
+                                   device=device, want_smooth=smooth, want_filter_mean=smooth, window_ids=[window_id], **kw)
+    _check_status(res["status"], "estimatemodel")
     s = _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
     if smooth:
         s.πb_mean = res["pi_smooth_mean"][0, :len(Y)]
@@ -210,7 +235,7 @@ def estimatesignals(opt, device=0):
     if not len(opt.signalRange):
         raise ValueError("estimatesignals needs a signalRange")
     if opt.σsignal == 0:                                   # isapprox(opt.σsignal, 0) (:869)
-        base = estimatemodel(opt, device=device)
+        base = estimatemodel(opt, device=device, window_id=BASE_RUN_STREAM)
         opt.σsignal = float(np.mean(base.σ)) * opt.noise  # :871
     Y = makey(opt)
     sig, sv = _sig_ranges(opt)
@@ -224,6 +249,7 @@ def estimatesignals(opt, device=0):
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
                                    device=device, sig_range=[sig], save_range=[sv], sigma_signal=[opt.σsignal],
                                    kappa=opt.noise, n_samples=ns, alpha=2.0, nu=2.0, **kw)
+    _check_status(res["status"], "estimatesignals")
     for k in unset:
         res["fcast"][0, 2 * k:2 * k + 2] = np.nan
     s = _unpack(res, 0, ns * n, opt.D, len(opt.horizons), enddate(opt))
@@ -263,8 +289,9 @@ def estimatesignalswindows(opts, device=0, window_ids=None):
     if need:                                               # base runs (:869-872): kappa = 1, alpha = nu = 1, no noise
         idx = np.array(need)
         base = _lib.estimate_batch_host(Y[idx], Tw[idx], o0.D, o0.burnin, o0.Nrun, tuple(o0.horizons), yreal[idx], seed=o0.seed,
-                                        device=device, want_draws=("sig2",), window_ids=wid[idx], sig_range=sig[idx],
+                                        device=device, want_draws=("sig2",), window_ids=wid[idx] | np.uint32(BASE_RUN_STREAM), sig_range=sig[idx],
                                         save_range=sv[idx], sigma_signal=np.zeros(len(idx)), kappa=1.0, n_samples=1)
+        _check_status(base["status"], "estimatesignalswindows (base run)")
         for i, w in enumerate(need):
             opts[w].σsignal = float(np.mean(base["sig2"][i].T.copy())) * opts[w].noise     # :871 (summed as estimatesignals does)
     n, ns = o0.signalNrun, o0.noiseSamples
@@ -275,6 +302,7 @@ def estimatesignalswindows(opts, device=0, window_ids=None):
     res = _lib.estimate_batch_host(Y, Tw, o0.D, o0.signalburnin, n, tuple(dev_h), yreal, seed=o0.seed, device=device,
                                    window_ids=wid, sig_range=sig, save_range=sv, sigma_signal=[o.σsignal for o in opts],
                                    kappa=o0.noise, n_samples=ns, alpha=2.0, nu=2.0, **kw)
+    _check_status(res["status"], "estimatesignalswindows")
     for k, h in enumerate(o0.horizons):
         if h < sigLen:
             res["fcast"][:, 2 * k:2 * k + 2] = np.nan

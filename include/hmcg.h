@@ -70,6 +70,8 @@ extern "C" {
 #define HMCG_ST_GAMMA_CAP      8 /* gamma rejection sampler hit its attempt cap */
 #define HMCG_ST_BAD_T         16 /* T[w] < 2, T[w] > ldY, T[w] beyond what max_T was sized for, or end_pos[w] outside
                                       [T-1-HMCG_MAXTAIL, T-1]: window skipped */
+#define HMCG_ST_BAD_RANGE     32 /* signal path: sig_range[w] / save_range[w] outside [0, T[w]], a non-empty sig_range not ending
+                                      at T[w], or a save_range longer than nsave_ld: window skipped */
 
 /* flags */
 #define HMCG_FLAG_RESUME 1  /* chain state (extras.xstate) is loaded instead of the makeParams init; sweep numbering continues at sweep_base */

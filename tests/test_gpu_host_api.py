@@ -67,7 +67,8 @@ def test_estimatesignals_like_run_hmm_allsignal(hmclib, oracle, inflation, tmp_p
     assert samples.signalvals.shape == (150, 2) and list(samples.signalids[:31]) == [1] * 30 + [2]
     assert (samples.signalvals[:30] == samples.signalvals[0]).all() and (samples.signalvals[30] != samples.signalvals[0]).any()
     # the same flow on the oracle: base run (kappa = 1, alpha = nu = 1), then the chained noise samples
-    base = oracle.estimate_signals(y[:e], 3, 200, 400, 1, sig=(0, e), kappa=1.0, alpha=1.0, nu=1.0, yreal=[y[e + 11]])
+    base = oracle.estimate_signals(y[:e], 3, 200, 400, 1, sig=(0, e), kappa=1.0, alpha=1.0, nu=1.0, yreal=[y[e + 11]],
+                                   window_id=hmc.BASE_RUN_STREAM)       # the base run has its own RNG stream
     ssig = base["sig2"].mean() * 0.3
     assert abs(ssig - opt.σsignal) < 1e-9 * (1 + ssig)
     o = oracle.estimate_signals(y[:e], 3, 20, 30, 5, sig=(0, e), kappa=0.3, alpha=2.0, nu=2.0, sigma_signal=opt.σsignal,
@@ -94,7 +95,7 @@ def test_estimatesignals_like_run_hmm_future_signals(hmclib, oracle, inflation, 
     s = hmc.estimatesignals(opt)
     T = e + signalLen
     base = oracle.estimate_signals(y[:T], 3, 100, 200, 1, sig=(e, T), kappa=1.0, alpha=1.0, nu=1.0, horizons=(6, 12, 24),
-                                   yreal=[y[e + 5], y[e + 11], y[e + 23]])
+                                   yreal=[y[e + 5], y[e + 11], y[e + 23]], window_id=hmc.BASE_RUN_STREAM)
     assert abs(base["sig2"].mean() * 1.0 - opt.σsignal) < 1e-9 * (1 + opt.σsignal)
     dev_h = [h - signalLen if h > signalLen else 0 for h in (6, 12, 24)]
     blend = 2 if signalLen == 12 else 0

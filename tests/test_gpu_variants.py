@@ -1,0 +1,136 @@
+"""One oracle-parity case for EVERY dispatchable kernel instantiation of csrc/variants_*.hip.
+
+Each row of the variant tables (K, steps per thread L, path, flavour) is driven with a window long enough to select
+exactly that row (256*(L/2) < T <= 256*L), forced to the flavour under test, run as a free chain for a few sweeps
+and compared with the oracle: state paths bit-exact, floats within 1e-9 relative-to-(1+|x|).  The call's own
+report (steps_per_thread, helper_waves) asserts that the intended instantiation ran.  VERDICT r1 item 2: the
+spill-heavy neighbours of the round-1 fault (K=3 L=16 base, SIG/SMOOTH L=8) had no parity test."""
+import re
+import os
+
+import numpy as np
+import pytest
+
+from hmc_jl_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hmc.jl_amd", "csrc")
+
+
+def variant_rows():
+    """(K, L, path) triples parsed from the HMCG_V3 rows of the variant tables (three flavours each)."""
+    rows = []
+    for fn in ("variants_k2.hip", "variants_k3.hip", "variants_k4.hip", "variants_sig.hip", "variants_smooth.hip"):
+        text = open(os.path.join(CSRC, fn)).read()
+        for m in re.finditer(r"HMCG_V3\((\d+),\s*(\d+),\s*(true|false),\s*(true|false)", text):
+            K, L, sig, sm = int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true"
+            rows.append((K, L, "sig" if sig else ("smooth" if sm else "base")))
+    return rows
+
+
+ROWS = variant_rows()
+CASES = [(K, L, path, fl) for (K, L, path) in ROWS for fl in ("p1", "p2", "h")]
+
+
+def close(g, o):
+    return float(np.max(np.abs(g - o) / (1.0 + np.abs(o)))) if g.size else 0.0
+
+
+def test_variant_tables_are_covered():
+    """The parser sees every row (the counts are those of the tables; a new row is picked up automatically)."""
+    assert len(ROWS) >= 33 and (3, 16, "base") in ROWS and (3, 8, "sig") in ROWS and (3, 8, "smooth") in ROWS
+
+
+@pytest.mark.parametrize("K,L,path,flavour", CASES, ids=["K%d-L%d-%s-%s" % c for c in CASES])
+def test_every_variant_against_oracle(hmclib, oracle, monkeypatch, K, L, path, flavour):
+    monkeypatch.setenv("HMCG_FLAVOUR", flavour)
+    Tmax = 256 * L - (1 if L > 1 else 0)               # odd length just under the variant's capacity (L=1: 256)
+    Tmin = 256 * (L // 2) + 1 if L > 1 else 2          # shortest window that still selects this L
+    lens = [Tmax, max(Tmin, Tmax - 129)]
+    Y, Tw, fut = synth.generate_panel(2, Tmax, K, ragged=lens)
+    burnin, nrun, horizons = 2, 5, (1, 12)
+    yreal = fut[:, [0, 11]]
+    ids = np.array([3, 8])
+    if path == "sig":
+        sig = np.stack([Tw - np.array([40, 1]), Tw], axis=1).astype(np.int32)
+        save = np.stack([Tw - 2, Tw], axis=1).astype(np.int32)
+        ssig = np.array([0.5, 1.0])
+        g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, horizons, yreal, want_state=True, window_ids=ids,
+                                     sig_range=sig, save_range=save, sigma_signal=ssig, kappa=0.6, n_samples=2,
+                                     alpha=2.0, nu=2.0)
+    else:
+        g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, horizons, yreal, want_state=True, window_ids=ids,
+                                     want_smooth=(path == "smooth"), want_filter_mean=(path == "smooth"))
+    assert g["steps_per_thread"] == L and g["threads_per_window"] == 256, (g["steps_per_thread"], L)
+    assert g["helper_waves"] == (4 if flavour == "h" else 0)
+    for w in range(2):
+        T = int(Tw[w])
+        if path == "sig":
+            o = oracle.estimate_signals(Y[w, :T], K, burnin, nrun, 2, sig=tuple(sig[w]), kappa=0.6, alpha=2.0, nu=2.0,
+                                        sigma_signal=float(ssig[w]), save=tuple(save[w]), horizons=horizons,
+                                        yreal=yreal[w], window_id=int(ids[w]))
+            assert close(g["sigvals"][w][:, :2], o["sigvals"]) < TOL
+        else:
+            o = oracle.estimate_window(Y[w, :T], K, burnin, nrun, horizons, yreal[w], window_id=int(ids[w]),
+                                       want_smooth=(path == "smooth"))
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :T], o["x_final"]), "state path differs (window %d)" % w
+        assert close(g["mu"][w].T, o["mu"]) < TOL and close(g["sig2"][w].T, o["sig2"]) < TOL
+        assert close(np.transpose(g["A"][w], (2, 1, 0)), o["A"]) < TOL
+        assert close(g["pi_end"][w].T, o["pi_end"]) < TOL and close(g["fcast"][w].T, o["fcast"]) < TOL
+        assert close(g["summary"][w], o["summary"]) < TOL
+        assert close(g["pif_final"][w, :T], o["pif_final"]) < TOL
+        if path == "smooth":
+            assert np.max(np.abs(g["pi_smooth_mean"][w, :T] - o["pi_smooth"].mean(axis=0))) < TOL
+
+
+@pytest.mark.parametrize("T", [2049, 3000, 4096])
+def test_k3_sixteen_steps_per_thread_lengths(hmclib, oracle, T):
+    """K = 3, T in 2049..4096: the L = 16 register-resident kernels (the table prefers the plain flavour there),
+    default dispatch, longer chain than the per-variant sweep above."""
+    Y, Tw, fut = synth.generate_panel(2, T, 3, ragged=[T, T - 500])
+    g = _lib.estimate_batch_host(Y, Tw, 3, 3, 12, (12,), fut[:, 11:12], want_state=True)
+    assert g["steps_per_thread"] == 16
+    for w in range(2):
+        o = oracle.estimate_window(Y[w, :Tw[w]], 3, 3, 12, (12,), fut[w, 11:12], window_id=w)
+        assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"])
+        for k, go in (("mu", g["mu"][w].T), ("sig2", g["sig2"][w].T), ("A", np.transpose(g["A"][w], (2, 1, 0))),
+                      ("pi_end", g["pi_end"][w].T), ("fcast", g["fcast"][w].T), ("summary", g["summary"][w]),
+                      ("pif_final", g["pif_final"][w, :Tw[w]])):
+            assert close(go, o[k]) < TOL, (w, k)
+
+
+def test_bad_signal_ranges_are_flagged_not_written(hmclib):
+    """sig_range / save_range are caller data.  A save range longer than nsave_ld, a range outside the
+    window, or a non-empty signal range that does not end at T must flag the window (HMCG_ST_BAD_RANGE) and write
+    nothing -- not index past the sigvals slab."""
+    import ctypes as C
+    Y, Tw, fut = synth.generate_panel(3, 300, 3)
+    L = _lib.load()
+    W, K, nrun, ns, nsave = 3, 3, 4, 2, 2
+    sig = np.array([[290, 300], [290, 300], [290, 299]], dtype=np.int32)       # window 2: does not end at T
+    save = np.array([[290, 300], [298, 300], [298, 300]], dtype=np.int32)      # window 0: 10 positions into a 2-wide slab
+    sentinel = -7.25
+    flat = np.full(W * ns * nsave + 64, sentinel)                              # slack after the slabs to catch overruns
+    out = {k: np.zeros(s) for k, s in dict(mu=(W, K, ns * nrun), summary=(W, 3 * K + K * K + 2)).items()}
+    status = np.zeros(W, dtype=np.int32)
+    ex = _lib.Extras(); ex.struct_size = C.sizeof(_lib.Extras)
+    ssg = np.array([0.3, 0.3, 0.3])
+    ex.sig_range = sig.ctypes.data; ex.save_range = save.ctypes.data; ex.sigma_signal = ssg.ctypes.data
+    ex.sigvals = flat.ctypes.data; ex.nsave_ld = nsave
+    cfg = _lib.make_config(W, K, 300, 300, 1, nrun, (12,), kappa=0.5, n_samples=ns)
+    T32 = np.ascontiguousarray(Tw, dtype=np.int32)
+    yr = np.ascontiguousarray(fut[:, 11:12])
+    rc = L.hmcg_estimate_batch(C.byref(cfg), _lib._np_ptr(Y), _lib._np_ptr(T32), _lib._np_ptr(yr), _lib._np_ptr(out["mu"]),
+                               None, None, None, None, _lib._np_ptr(out["summary"]), _lib._np_ptr(status), C.byref(ex), None)
+    assert rc == 0
+    assert status[0] == _lib.ST_BAD_RANGE and status[2] == _lib.ST_BAD_RANGE and status[1] == 0
+    body = flat[:W * ns * nsave].reshape(W, ns, nsave)
+    assert (flat[W * ns * nsave:] == sentinel).all()                           # nothing past the buffer
+    assert (body[1] != sentinel).all() and (body[1] != 0).all()               # the valid window reported its values
+    assert (out["mu"][0] == 0).all() and (out["mu"][2] == 0).all() and (out["mu"][1] != 0).all()
+    # ... and exactly the values a call with that window alone reports (no neighbour wrote into its slab)
+    alone = _lib.estimate_batch_host(Y[1:2], Tw[1:2], K, 1, nrun, (12,), fut[1:2, 11:12], window_ids=[1], sig_range=sig[1:2],
+                                     save_range=save[1:2], sigma_signal=ssg[1:2], kappa=0.5, n_samples=ns)
+    assert np.array_equal(alone["sigvals"][0], body[1]) and np.array_equal(alone["mu"][0], out["mu"][1])

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""ISA lint for the gfx950 kernels of libhmcgibbs (run on the compiler's own assembly, csrc/obj/*.s).
+
+What it looks for -- the miscompile behind round 1's HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION:
+the backend placed a VGPR -> AGPR live-range copy (`v_accvgpr_write_b32 a0/a1`, the per-lane output pointer
+`out_base`) into the *prologue* of a join block, among the SGPR-spill `v_writelane`s and AHEAD of the
+`s_or_b64 exec, exec, s[..]` that re-activates the lanes of the other branch.  Those lanes kept whatever the
+AGPRs held before, later read it back as a pointer and stored through it.  Whether it happens depends on
+register allocation, i.e. on unrelated source changes, so every build is checked:
+
+  rule 1  in any basic block, no register-allocator copy (v_accvgpr_*, scratch_* spill/reload, plain v_mov vA, vB) may
+          sit between the block start and the exec-widening instruction that opens it (s_or_b64 exec, exec, sN /
+          s_or_saveexec_b64) when only prologue-class instructions (SALU, v_writelane/v_readlane, s_nop,
+          s_waitcnt) and other such copies precede it;
+  rule 2  no flat_* memory instruction (every access is global_*, scratch_* or ds_*) and no device-side function
+          call (an un-inlined lambda captures by reference: flat accesses, a stack, s_swappc).
+Kernels that spill to scratch are listed as warnings (a performance matter, not a correctness one).
+
+Exit status 1 when a rule fails.  Also prints, per kernel, VGPR/AGPR/spill/scratch/LDS figures (--table).
+"""
+import glob
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OBJ = os.path.join(os.path.dirname(HERE), "hmc.jl_amd", "csrc", "obj")
+
+# register-allocator traffic: AGPR copies, scratch spills/reloads, and plain VGPR->VGPR moves (live-range splits).  A
+# join block's first real instruction is the exec restore, so such an instruction ahead of it -- with nothing but
+# prologue-class instructions around it -- was put there by the allocator under the wrong exec mask.
+VEC_SPILL = re.compile(r"^\s*(v_accvgpr_(write|read|mov)_b32\s|scratch_(store|load)\w*\s|buffer_(store|load)\w*\s|"
+                       r"v_mov_b32_e32\s+v\d+,\s*v\d+\s*$|v_mov_b64_e32\s+v\[\d+:\d+\],\s*v\[\d+:\d+\]\s*$)")
+PROLOGUE_OK = re.compile(r"^\s*(s_|v_writelane_b32|v_readlane_b32)")
+# exec-WIDENING instructions that end a divergent region (SI_END_CF -> s_or_b64 exec, exec, sN) or flip to the else
+# side (s_or_saveexec_b64).  `s_and_b64 ..; s_mov_b64 exec, ..` NARROWS exec (a region begins): loads ahead of it are fine.
+EXEC_WIDEN = re.compile(r"^\s*(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64)")
+EXEC_OTHER = re.compile(r"^\s*s_\w+\s+exec,")
+BLOCK_START = re.compile(r"^(\.LBB\d+_\d+:|; %bb\.\d+:|[_A-Za-z][\w$.]*:)")
+KERNEL_START = re.compile(r"^(_Z\w+):\s")
+
+
+def lint_file(path):
+    problems, table = [], []
+    kernel = None
+    in_prologue = False
+    pending = []            # vector spill instructions seen in the current block prologue
+    with open(path) as f:
+        lines = f.readlines()
+    meta = {}
+    for n, raw in enumerate(lines, 1):
+        line = raw.split(";")[0].rstrip() if not raw.lstrip().startswith(";") else raw.rstrip()
+        m = KERNEL_START.match(raw)
+        if m:
+            kernel = m.group(1)
+        if BLOCK_START.match(raw.strip()) or BLOCK_START.match(raw):
+            in_prologue, pending = True, []
+            continue
+        s = line.strip()
+        if not s or s.startswith(";") or s.startswith("."):
+            mm = re.match(r"\s*\.(amdhsa_\w+|\w+):?\s+(\S+)", raw)
+            continue
+        if re.match(r"^\s*flat_", line):
+            problems.append((path, n, kernel, "flat_* memory instruction", s))
+        if re.match(r"^\s*(s_swappc_b64|s_setpc_b64|s_call_b64)", line):
+            problems.append((path, n, kernel, "function call / return (a device lambda was not inlined)", s))
+        if in_prologue:
+            if EXEC_WIDEN.match(line):
+                if pending:
+                    for pn, ps in pending:
+                        problems.append((path, pn, kernel, "vector spill/copy ahead of the exec restore at line %d" % n, ps))
+                in_prologue = False      # one exec restore per prologue is what the backend emits; stop here
+            elif EXEC_OTHER.match(line):
+                in_prologue = False      # exec narrowed / rewritten: not the join pattern
+            elif VEC_SPILL.match(line):
+                pending.append((n, s))
+            elif PROLOGUE_OK.match(line):
+                pass
+            else:
+                in_prologue = False
+    # resource table from the metadata notes (one YAML-ish block per kernel)
+    cur = {}
+    for raw in lines:
+        m = re.match(r"\s+- \.agpr_count:\s+(\d+)", raw) or re.match(r"\s+\.agpr_count:\s+(\d+)", raw)
+        if m:
+            cur["agpr"] = int(m.group(1))
+        for key, pat in (("lds", r"\.group_segment_fixed_size:\s+(\d+)"), ("scratch", r"\.private_segment_fixed_size:\s+(\d+)"),
+                         ("sgpr_spill", r"\.sgpr_spill_count:\s+(\d+)"), ("vgpr", r"\.vgpr_count:\s+(\d+)"),
+                         ("vgpr_spill", r"\.vgpr_spill_count:\s+(\d+)"), ("name", r"\.name:\s+(\S+)")):
+            m = re.match(r"\s+(?:- )?" + pat, raw)
+            if m:
+                cur[key] = m.group(1) if key == "name" else int(m.group(1))
+        if "vgpr_spill" in cur and "name" in cur and "vgpr" in cur and "lds" in cur:
+            table.append(cur)
+            cur = {}
+    return problems, table
+
+
+def demangle_short(name):
+    m = re.search(r"gibbs_sweeps_kernel(_big)?I(.*?)EEvNS", name)
+    if not m:
+        return name[:60]
+    args = re.findall(r"L[ib](\d+)E", m.group(2))
+    return "gibbs%s<%s>" % (m.group(1) or "", ",".join(args))
+
+
+def main():
+    paths = [a for a in sys.argv[1:] if not a.startswith("--")] or sorted(glob.glob(os.path.join(OBJ, "*gfx950*.s")))
+    if not paths:
+        print("isa_lint: no assembly found under %s (build with `make -C hmc.jl_amd/csrc`)" % OBJ)
+        return 2
+    bad = 0
+    for p in paths:
+        problems, table = lint_file(p)
+        if "--table" in sys.argv:
+            for k in table:
+                print("%-34s vgpr %3d agpr %3d vspill %3d sspill %3d scratch %4d lds %6d" % (
+                    demangle_short(k["name"]), k.get("vgpr", -1), k.get("agpr", 0), k.get("vgpr_spill", 0),
+                    k.get("sgpr_spill", 0), k.get("scratch", 0), k.get("lds", 0)))
+        if "--table" not in sys.argv:
+            scr = [demangle_short(k["name"]) + ":%dB" % k["scratch"] for k in table if k.get("scratch", 0) > 0]
+            if scr:
+                print("warning: %s: scratch spills in %s" % (os.path.basename(p).split("-hip-")[0], " ".join(scr)))
+        for path, n, kernel, what, text in problems:
+            bad += 1
+            print("%s:%d: [%s] %s: %s" % (os.path.basename(path), n, demangle_short(kernel or "?"), what, text))
+    print("isa_lint: %d file(s), %d problem(s)" % (len(paths), bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
