@@ -3,7 +3,6 @@
 (BASELINE.json configs[1]: K=3, T=1000, 256 windows, 1000 draws per GPU).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one batched estimate call (hmcg_estimate_batch_device) over this rank's 256
 windows with inputs already resident in HBM: 0 burn-in + 1000 kept sweeps per window,
@@ -11,20 +10,29 @@ h=12 forecast per draw, on-device summary means; for N > 1 the step ends with th
 exchange of the path, the gather of the per-window summary blocks to rank 0 (RCCL).
 Weak scaling: every GPU gets its own 256 windows (global window ids, so the sharded run
 equals the unsharded one).  One JSON line is printed by rank 0.
+
+Launch: with N > 1 and no WORLD_SIZE in the environment this process touches no GPU; it
+starts `python -m torch.distributed.run --nproc-per-node N` on this same file as a child
+(one rank per GPU) and relays rank 0's JSON line.  Under torchrun (WORLD_SIZE set) it is a rank.
+
+At N = 1 the line also carries `extra`: the other shapes of BASELINE.json and the end-to-end
+(host buffers in, all per-draw outputs out) rate of the headline shape, each measured after the
+headline timed region.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 K, T, W_PER_GPU, DRAWS, HORIZON = 3, 1000, 256, 1000, 12
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0   # ... ~6.3 TB/s measured copy bandwidth (SURVEY.md 8d asks for both fractions)
 
 
 def algorithmic_bytes_per_draw(T_, K_, H_):
@@ -77,6 +85,89 @@ def cpu_baseline(Y, Tw, yreal):
     return out
 
 
+def kernel_name(K_, tm, sig=False, smooth=False):
+    if K_ >= 5 or tm.steps_per_thread > 16:
+        return "hmcg::gibbs_sweeps_kernel_big<%d,%d>" % (K_, tm.threads_per_window)
+    return "hmcg::gibbs_sweeps_kernel<%d,%d,%d,%s,%s,%d,%d>" % (
+        K_, tm.steps_per_thread, tm.threads_per_window, str(sig).lower(), str(smooth).lower(), tm.helper_waves,
+        2 if tm.helper_waves else 0)
+
+
+def shape_record(name, K_, lens, draws, reps=3, device=0):
+    """One device-resident call of another BASELINE shape: kernel time from HIP events on the launch stream."""
+    import numpy as np
+    from hmc_jl_amd import device as hdev, synth
+    W = len(lens)
+    Tmax = int(max(lens))
+    ragged = None if len(set(lens)) == 1 else list(lens)
+    Y, Tw, fut = synth.generate_panel(W, Tmax, K_, horizon_pad=HORIZON, ragged=ragged)
+    panel = hdev.DevicePanel(Y, Tw, K_, draws, (HORIZON,), fut[:, HORIZON - 1:HORIZON], device=device, keep_draws=True)
+    panel.run(burnin=0)
+    ms = [panel.run(burnin=0) for _ in range(reps)]
+    tm = panel.last_timing
+    k_ms = float(np.mean(ms))
+    by = float(sum(algorithmic_bytes_per_draw(int(t), K_, 1) for t in lens)) * draws
+    ach = by / (k_ms * 1e-3) / 1e9
+    rec = {"workload": name, "K": K_, "windows": W, "T_min": int(min(lens)), "T_max": Tmax, "draws_per_window": draws,
+           "kernel": kernel_name(K_, tm), "kernel_ms": k_ms, "value": W * draws / (k_ms * 1e-3), "unit": "Gibbs draws/s",
+           "algorithmic_bytes_per_launch": by, "achieved_GBps": ach, "frac_of_8000": ach / HBM_PEAK_GBS,
+           "frac_of_6300": ach / HBM_ACHIEVABLE_GBS, "steps_per_thread": tm.steps_per_thread,
+           "helper_waves": tm.helper_waves, "lds_bytes_per_window": tm.lds_bytes,
+           "windows_flagged": int((panel.status != 0).sum().item())}
+    del panel
+    return rec
+
+
+def end_to_end_record(Y, Tw, yreal, reps=5):
+    """SURVEY.md 8(d)'s wall-clock definition on the headline shape: pageable host arrays in (H2D of the Y panel), every
+    per-draw output back in the caller's pageable arrays (41 MB), through hmcg_estimate_batch."""
+    import numpy as np
+    from hmc_jl_amd import _lib
+    for _ in range(2):
+        r = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal)
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal)
+        t.append(time.perf_counter() - t0)
+    ms = float(np.median(t)) * 1e3
+    t2 = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r2 = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal, want_draws=False)
+        t2.append(time.perf_counter() - t0)
+    ms2 = float(np.median(t2)) * 1e3
+    nbytes = sum(r[k].nbytes for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "status"))
+    return {"workload": "configs[1] through the host entry: H2D of Y, %d chunked launches, D2H of all per-draw outputs "
+                        "(%.1f MB) into pageable caller arrays" % (r["launches"], nbytes / 1e6),
+            "ms_per_call": ms, "value": W_PER_GPU * DRAWS / (ms * 1e-3), "unit": "Gibbs draws/s",
+            "library_call_ms": r["call_ms"], "kernel_ms_sum": r["kernel_ms"], "launches": r["launches"],
+            "summary_only_ms_per_call": ms2, "summary_only_value": W_PER_GPU * DRAWS / (ms2 * 1e-3),
+            "note": "ms_per_call includes the Python wrapper's output allocation (np.zeros, 41 MB); library_call_ms is "
+                    "the wall time inside hmcg_estimate_batch"}
+
+
+def spawn_ranks(args):
+    """Parent of an N-GPU run: no torch.cuda, no HIP call here -- the ranks are fresh child processes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line:
+        print(line, flush=True)
+    else:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if proc.returncode else (0 if line else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,21 +175,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--threads-per-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra shapes (profiling runs of the headline kernel)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="multi-rank plumbing rehearsal on a one-GPU box: every rank uses cuda:0 and the process group "
                          "is gloo (RCCL refuses two ranks on one device); never used for reported numbers")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
-    import hmc_jl_amd
+    import hmc_jl_amd  # noqa: F401
     from hmc_jl_amd import device as hdev, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: hmc.jl_amd has no CPU fallback")
     if args.rehearse_shared_gpu:
@@ -169,14 +265,28 @@ def main():
                        "helper_waves": tm.helper_waves, "lds_bytes_per_window": tm.lds_bytes, "windows_flagged": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hmcg::gibbs_sweeps_kernel<3,%d,%d,false,false,%d,2>" % (tm.steps_per_thread, tm.threads_per_window, tm.helper_waves),
+                         "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                         "kernel": kernel_name(K, tm),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": B * W_PER_GPU * DRAWS,
                          "note": "algorithmic bytes = 58160 B/draw (SURVEY 8d) x 256 windows x 1000 draws; the chain "
-                                 "state is register/LDS-resident, so the physical limiter is fp64 VALU latency, not HBM"},
+                                 "state is register/LDS-resident, so the physical limiter is fp64 VALU issue, not HBM"},
         }
+        if world == 1 and not args.no_extra:
+            del panel
+            extra = {}
+            try:
+                extra["end_to_end_host_entry"] = end_to_end_record(Y, Tw, yreal)
+                extra["cfg4_k8_T5000_w512"] = shape_record("configs[3]: 8-state, T=5000, 512 windows, 1000 draws", 8, [5000] * 512, 1000, reps=2)
+                extra["production_460_expanding"] = shape_record(
+                    "the reference's production shape (code/run_hmm.jl:79-109): 460 expanding windows T=120..579, K=3, 1000 draws",
+                    3, list(range(120, 580)), 1000)
+                extra["w2048_T1000"] = shape_record("configs[2] on one GPU: 3-state, T=1000, 2048 windows, 1000 draws", 3, [1000] * 2048, 1000)
+            except Exception as e:                      # the headline line must still be printed
+                extra["error"] = repr(e)
+            line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Y, Tw, yreal)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

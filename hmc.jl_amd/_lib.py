@@ -23,7 +23,8 @@ ST_SKIPPED = ST_NONFINITE | ST_BAD_T | ST_BAD_RANGE      # the window was not co
 
 HMCG_MAXTAIL = 32
 EXPORTS = ("hmcg_version", "hmcg_device_count", "hmcg_last_error", "hmcg_shutdown",
-           "hmcg_estimate_batch", "hmcg_estimate_batch_device")
+           "hmcg_estimate_batch", "hmcg_estimate_batch_device", "hmcg_estimate_batch_multi")
+HMCG_MAXDEV = 16
 
 
 class HmcgError(RuntimeError):
@@ -50,7 +51,7 @@ class Extras(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int32), ("threads_per_window", C.c_int32),
                 ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32), ("helper_waves", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("call_ms", C.c_double), ("windows", C.c_int32), ("reserved", C.c_int32)]
 
 
 _LIB = None
@@ -107,6 +108,7 @@ def load():
         L.hmcg_shutdown.restype = None
         L.hmcg_estimate_batch.restype = C.c_int
         L.hmcg_estimate_batch_device.restype = C.c_int
+        L.hmcg_estimate_batch_multi.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -147,10 +149,11 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
-                        end_pos=None, blend_mask=0, want_filter_mean=False):
+                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
-    A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,)."""
+    A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,).
+    devices: a list of HIP ordinals -> hmcg_estimate_batch_multi (windows partitioned over those GPUs)."""
     L = load()
     Y = np.ascontiguousarray(Y, dtype=np.float64)
     W, ldY = Y.shape
@@ -215,11 +218,21 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         ex.sumacc = out["sumacc"].ctypes.data
     cfg = make_config(W, K, ldY, min(int(T.max()), ldY), burnin, nrun, horizons, seed, window_base, device, flags,
                       threads_per_window, sweep_base, alpha, nu, sweep_count, kappa, n_samples, blend_mask)
-    tm = Timing()
-    rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
-                               _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),
-                               _np_ptr(out.get("pi_end")), _np_ptr(out.get("fcast")), _np_ptr(out["summary"]),
-                               _np_ptr(out["status"]), C.byref(ex), C.byref(tm))
+    if devices is None:
+        tm = Timing()
+        rc = L.hmcg_estimate_batch(C.byref(cfg), _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
+                                   _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),
+                                   _np_ptr(out.get("pi_end")), _np_ptr(out.get("fcast")), _np_ptr(out["summary"]),
+                                   _np_ptr(out["status"]), C.byref(ex), C.byref(tm))
+        tms = [tm]
+    else:
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        tms = (Timing * len(devices))()
+        rc = L.hmcg_estimate_batch_multi(C.byref(cfg), C.c_int32(len(devices)), devs, _np_ptr(Y), _np_ptr(T), _np_ptr(yr),
+                                         _np_ptr(out.get("mu")), _np_ptr(out.get("sig2")), _np_ptr(out.get("A")),
+                                         _np_ptr(out.get("pi_end")), _np_ptr(out.get("fcast")), _np_ptr(out["summary"]),
+                                         _np_ptr(out["status"]), C.byref(ex), tms)
+        tm = tms[0]
     _check(rc)
     # a skipped window (non-finite data, bad T, bad ranges) was not computed: its outputs read NaN, never a
     # plausible-looking zero (the reference would have thrown, src/Hmc.jl:435)
@@ -233,6 +246,10 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     out["steps_per_thread"] = tm.steps_per_thread
     out["lds_bytes"] = tm.lds_bytes
     out["helper_waves"] = tm.helper_waves
+    out["launches"] = tm.launches
+    out["call_ms"] = max(t.call_ms for t in tms)
+    out["per_device"] = [dict(device=t.device, windows=t.windows, kernel_ms=t.kernel_ms, call_ms=t.call_ms, launches=t.launches)
+                         for t in tms]
     return out
 
 

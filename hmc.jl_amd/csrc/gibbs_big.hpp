@@ -233,7 +233,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         const int d = sw >= p.burnin_s ? sw - p.burnin_s : -1;       // one sample per launch on this path
         if (d < 0) return;
         const ThetaBufBig<K>& th = sh.th[sw & 1];
-        const size_t nrun = (size_t)p.nd;
+        const size_t nrun = (size_t)p.nd_ld;
+        const int dcol = d - p.draw_off;                 // column of this draw in this launch's output arrays
         if (wave == OUT_WAVE) {
             double mu_u[K];
             int order[K];
@@ -253,14 +254,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                         for (int qq = 0; qq < K; ++qq) src = (qq == pos) ? order[qq] : src;
                         val = which == 0 ? th.mu[src] : (which == 1 ? th.sig2[src] : th.pi_end[src]);
                         double* base = which == 0 ? p.mu : (which == 1 ? p.sig2 : p.pi_end);
-                        if (base) dst = base + nrun * ((size_t)pos + (size_t)K * w) + d;
+                        if (base) dst = base + nrun * ((size_t)pos + (size_t)K * w) + dcol;
                     } else {
                         const int e = orole - 3 * K;                 // column-major e = i + K*j
                         int si = 0, sj = 0;
 #pragma unroll
                         for (int qq = 0; qq < K; ++qq) { si = (qq == e % K) ? order[qq] : si; sj = (qq == e / K) ? order[qq] : sj; }
                         val = th.A[si][sj];
-                        if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + d;
+                        if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + dcol;
                     }
                     if (dst) *dst = val;
                     sum_par[q] += round5(val);
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         if (fc_e >= 0) {
             const double fv = sh.fcval[fc_e >> 1];
             const double val = (fc_e & 1) ? fv - fc_yr : fv;
-            if (p.fcast) p.fcast[nrun * ((size_t)fc_e + (size_t)(2 * p.H) * w) + d] = val;
+            if (p.fcast) p.fcast[nrun * ((size_t)fc_e + (size_t)(2 * p.H) * w) + dcol] = val;
             sum_fc += round5(val);
         }
     };

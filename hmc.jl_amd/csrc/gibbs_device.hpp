@@ -61,6 +61,10 @@ struct KernelParams {
     // d of global sweep g is (g / per_sample) * nrun_s + (g % per_sample - burnin_s); nd = n_samples * nrun_s
     // is the leading dimension of the per-draw outputs.  n_samples == 1 is the estimatemodel case.
     int32_t per_sample, burnin_s, nrun_s, n_samples, nd;
+    // The per-draw output arrays of THIS launch hold draws [draw_off, draw_off + nd_ld): leading dimension nd_ld, kept
+    // draw d is stored at column index d - draw_off.  (nd_ld = nd, draw_off = 0 when one launch covers the whole run; the
+    // host entry runs long chains in chunks whose outputs stream to the caller while the next chunk samples.)
+    int32_t nd_ld, draw_off;
     // signal Monte-Carlo path (estimatesignals!, src/Hmc.jl:868-914); all null/zero for estimatemodel
     double kappa;                   // hp.kappa: relative noise of a signal observation
     const int32_t* sig_range;       // [W][2] signal positions [begin, end) (end == T)
@@ -490,15 +494,17 @@ __device__ __forceinline__ uint32_t map_compose(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ int map_apply(uint32_t m, int s) { return (int)((m >> (4 * s)) & 15u); }
 
-// Julia round(x; digits=5) (basicsave, src/Hmc.jl:719)
+// Julia round(x; digits=5) (basicsave, src/Hmc.jl:719) = rint(x * 1e5) / 1e5 with a CORRECTLY ROUNDED quotient, as the
+// oracle and a host-side mean of the per-draw CSV cells compute it: reciprocal estimate q0 = fl(n * 1e-5), exact fp64
+// residual r = n - q0 * 1e5 (one FMA), correction q0 + r * 1e-5.  For |n| < 2^53 the corrected value is the correctly
+// rounded n / 1e5 (Markstein's division sequence with an exact residual; 1e-5 is 1/1e5 to half an ulp).
 __device__ __forceinline__ double round5(double x)
 {
-    // rint(x * 1e5) / 1e5 with the quotient from a reciprocal multiply and one residual correction (the
-    // result differs from the correctly rounded quotient by at most an ulp; the summary tolerance is 1e-9)
     const double n = rint(x * 1e5);
-    const double q = n * 1e-5;
-    const double r = fma(fma(-q, 1e5, n), 1e-5, q);
-    return isfinite(r) ? r : x;
+    const double q0 = n * 1e-5;
+    const double r = fma(-q0, 1e5, n);
+    const double q = fma(r, 1e-5, q0);
+    return isfinite(q) ? q : x;
 }
 
 // forecast (src/Hmc.jl:658-667): (pi' A^h) . mu, A^h on Julia's power_by_squaring schedule.
@@ -927,7 +933,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     bool fc_blend = false;                // signal path: this horizon is a forecastsignal blend
     double fc_yr = 0.0;
     {
-        const size_t nrun = (size_t)p.nd;
+        const size_t nrun = (size_t)p.nd_ld;
         if (orole >= 0 && orole < 3 * K) {
             o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
             double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
@@ -1054,7 +1060,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 }
             }
         }
-        if (out_base) out_base[d] = val;
+        if (out_base) out_base[d - p.draw_off] = val;
         sum_acc += round5(val);
     };
 

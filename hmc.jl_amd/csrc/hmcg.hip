@@ -1,15 +1,28 @@
 // hmcg.hip -- host side of libhmcgibbs.so (C ABI in include/hmcg.h).
-// Owns the lazily created per-process context (stream, events), validates
-// arguments, picks the kernel instantiation for (K, max_T, threads_per_window)
-// and launches the persistent per-window sweep kernel.  No CPU compute path
-// exists here: without a HIP device every compute entry returns HMCG_E_NODEVICE.
+//
+// One lazily created context per HIP device: a compute stream, a copy stream, events and two grow-only
+// workspaces (device memory and pinned host staging), so that a call costs no hipMalloc/hipFree once the
+// workspaces have reached the size of the largest call.  Calls on one device are serialised by the context's
+// mutex; different devices run concurrently (hmcg_estimate_batch_multi drives one host thread per device).
+//
+// The host entries stream results: a long chain is cut into a few chunks (big first, small last); chunk c's
+// per-draw outputs go by SDMA into pinned staging and from there into the caller's arrays while chunk c+1
+// samples.  The chain state between chunks travels through the same checkpoint block (xstate, sumacc) that
+// HMCG_FLAG_RESUME exposes, so a chunked run is bit-identical to a single launch.
+//
+// No CPU compute path exists here: without a HIP device every compute entry returns HMCG_E_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "variants.hpp"
@@ -17,7 +30,6 @@
 namespace {
 
 thread_local char g_err[512] = "";
-std::mutex g_mu;
 
 void set_err(const char* fmt, ...)
 {
@@ -36,36 +48,106 @@ void set_err(const char* fmt, ...)
         }                                                                              \
     } while (0)
 
-struct Context {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int cu_count = 0;
+// Grow-only allocation (device memory or pinned host memory).  Growing frees and reallocates: callers lay out a
+// whole call before taking pointers, and nothing survives from one call to the next.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        release();
+        const size_t want = std::max(n + n / 4, (size_t)1 << 20);
+        hipError_t e = pinned ? hipHostMalloc((void**)&base, want, hipHostMallocDefault) : hipMalloc((void**)&base, want);
+        if (e != hipSuccess) {
+            base = nullptr;
+            // retry with exactly what is needed before giving up
+            e = pinned ? hipHostMalloc((void**)&base, n, hipHostMallocDefault) : hipMalloc((void**)&base, n);
+            if (e != hipSuccess) { base = nullptr; cap = 0; return HMCG_E_NOMEM; }
+            cap = n;
+            return 0;
+        }
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (base) { if (pinned) (void)hipHostFree(base); else (void)hipFree(base); }
+        base = nullptr; cap = 0;
+    }
 };
-Context g_ctx;
 
-int ensure_context(int device)
+// offsets into an arena, 256-byte aligned; pointers are taken after ensure()
+struct Layout {
+    size_t total = 0;
+    size_t add(size_t bytes) { const size_t off = total; total += (bytes + 255) & ~(size_t)255; return off; }
+};
+
+constexpr int RING = 3;            // chunk buffers in flight (device and pinned)
+
+struct DeviceCtx {
+    std::mutex mu;                 // serialises calls on this device
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr, copy = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;          // kernel timing
+    hipEvent_t evk[RING] = {}, evc[RING] = {};        // chunk pipeline: kernel done / copy done
+    int cu_count = 0;
+    Arena dev, pin;
+};
+DeviceCtx g_ctx[HMCG_MAXDEV];
+std::mutex g_init_mu;
+
+// Returns the (created on first use) context of `device`; the caller then locks ctx->mu and calls hipSetDevice.
+int get_context(int device, DeviceCtx** out)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         set_err("no HIP device available (libhmcgibbs has no CPU fallback)");
         return HMCG_E_NODEVICE;
     }
-    if (device < 0 || device >= n) {
-        set_err("device %d out of range (count %d)", device, n);
+    if (device < 0 || device >= n || device >= HMCG_MAXDEV) {
+        set_err("device %d out of range (count %d, at most %d)", device, n, HMCG_MAXDEV);
         return HMCG_E_BADARG;
     }
-    HIP_TRY(hipSetDevice(device));
-    if (g_ctx.device != device) {
-        if (g_ctx.stream) { (void)hipStreamDestroy(g_ctx.stream); (void)hipEventDestroy(g_ctx.ev0); (void)hipEventDestroy(g_ctx.ev1); }
-        g_ctx = Context{};
-        HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&g_ctx.ev0));
-        HIP_TRY(hipEventCreate(&g_ctx.ev1));
-        HIP_TRY(hipDeviceGetAttribute(&g_ctx.cu_count, hipDeviceAttributeMultiprocessorCount, device));
-        g_ctx.device = device;
+    DeviceCtx& c = g_ctx[device];
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (!c.ready) {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&c.ev0));
+        HIP_TRY(hipEventCreate(&c.ev1));
+        for (int i = 0; i < RING; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&c.evk[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c.evc[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, device));
+        c.pin.pinned = true;
+        c.device = device;
+        c.ready = true;
     }
+    *out = &c;
     return 0;
+}
+
+void destroy_context(DeviceCtx& c)
+{
+    if (!c.ready) return;
+    (void)hipSetDevice(c.device);
+    (void)hipStreamSynchronize(c.stream);        // nothing of ours may still be running when the streams go
+    (void)hipStreamSynchronize(c.copy);
+    (void)hipStreamDestroy(c.stream);
+    (void)hipStreamDestroy(c.copy);
+    (void)hipEventDestroy(c.ev0);
+    (void)hipEventDestroy(c.ev1);
+    for (int i = 0; i < RING; ++i) { (void)hipEventDestroy(c.evk[i]); (void)hipEventDestroy(c.evc[i]); }
+    c.dev.release();
+    c.pin.release();
+    c.stream = c.copy = nullptr;
+    c.ready = false;
+    c.device = -1;
 }
 
 using namespace hmcg_host;
@@ -108,14 +190,29 @@ int validate(const hmcg_config* cfg)
     }
     for (int h = 0; h < cfg->H; ++h)
         if (cfg->horizons[h] < 0) { set_err("negative horizon"); return HMCG_E_BADARG; }
+    if ((long long)(cfg->n_samples > 1 ? cfg->n_samples : 1) * ((long long)cfg->burnin + cfg->nrun) > 0x7fffffffLL) {
+        set_err("n_samples * (burnin + nrun) exceeds 2^31 - 1 sweeps");
+        return HMCG_E_BADARG;
+    }
     return 0;
 }
 
-int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, const double* dyreal, double* dmu,
-                  double* dsig2, double* dA, double* dpi_end, double* dfcast, double* dsummary, int32_t* dstatus,
-                  const hmcg_extras* ex, hipStream_t stream, hmcg_timing* timing)
+// What runs: the kernel instantiation for this call's shape, chosen once per call.
+struct Plan {
+    const Variant* v = nullptr;
+    const BigVariant* bv = nullptr;
+    int bigL = 0;
+    size_t dyn = 0;
+    bool use_sig = false, use_smooth = false;
+    int NT() const { return v ? v->NT : bv->NT; }
+    int L() const { return v ? v->L : bigL; }
+    int NH() const { return v ? v->NH : 0; }
+    const void* fptr() const { return v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn); }
+};
+
+// Argument checks common to both entries + kernel choice.  W is the number of windows THIS device runs.
+int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count, Plan* plan)
 {
-    if (!dY || !dT || !dstatus) { set_err("Y, T and status are required"); return HMCG_E_BADARG; }
     if (ex && ex->struct_size != (int32_t)sizeof(hmcg_extras)) { set_err("hmcg_extras.struct_size mismatch"); return HMCG_E_BADARG; }
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
     if (resume && !(ex && ex->xstate)) { set_err("HMCG_FLAG_RESUME needs extras.xstate"); return HMCG_E_BADARG; }
@@ -131,131 +228,507 @@ int launch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, c
         return HMCG_E_BADARG;
     }
     if (cfg->blend_mask < 0 || (cfg->H < 31 && (cfg->blend_mask >> cfg->H) != 0)) { set_err("blend_mask has bits beyond H"); return HMCG_E_BADARG; }
-    const bool use_smooth_req = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
-    if ((use_sig || use_smooth_req) && cfg->K >= 5) { set_err("signal path and smoothed / filtered means: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
-    const Variant* v = nullptr;
-    const BigVariant* bv = nullptr;
-    int bigL = 0;
-    size_t dyn = 0;
-    const bool use_smooth = use_smooth_req;
+    if (ex && ex->sigvals && ex->nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
+    const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
+    if ((use_sig || use_smooth) && cfg->K >= 5) { set_err("signal path and smoothed / filtered means: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     if (use_smooth && use_sig) { set_err("pi_smooth_mean / pi_filter_mean are not available on the signal path"); return HMCG_E_UNSUPPORTED; }
+    if (cfg->sweep_base > n_samples * (cfg->burnin + cfg->nrun)) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).
     // HMCG_FLAVOUR=p1|p2|h and HMCG_HELPERS=0|1 override the table (diagnostics, tools/variant_sweep.py).
-    const bool small_batch = cfg->W <= g_ctx.cu_count;
+    const bool small_batch = W <= cu_count;
     int force = -1;
     if (const char* henv = getenv("HMCG_HELPERS")) force = atoi(henv) != 0 ? H : (small_batch ? P1 : P2);
     if (const char* fenv = getenv("HMCG_FLAVOUR")) force = !strcmp(fenv, "h") ? H : (!strcmp(fenv, "p2") ? P2 : P1);
-    if (cfg->K < 5) v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
-    if (!v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
-        for (int i = 0; i < g_n_big_variants; ++i) if (g_big_variants[i].K == cfg->K) bv = &g_big_variants[i];
-        if (bv) {
-            bigL = (maxT + bv->NT - 1) / bv->NT;
-            dyn = (size_t)bv->NT * bigL * (8 + 8 + 4 + 1) + 16;
-            if (dyn > BIG_MAX_DYN_LDS || (cfg->threads_per_window != 0 && cfg->threads_per_window != bv->NT)) bv = nullptr;
+    Plan pl;
+    pl.use_sig = use_sig; pl.use_smooth = use_smooth;
+    if (cfg->K < 5) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
+    if (!pl.v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
+        for (int i = 0; i < g_n_big_variants; ++i) if (g_big_variants[i].K == cfg->K) pl.bv = &g_big_variants[i];
+        if (pl.bv) {
+            pl.bigL = (maxT + pl.bv->NT - 1) / pl.bv->NT;
+            pl.dyn = (size_t)pl.bv->NT * pl.bigL * (8 + 8 + 4 + 1) + 16;
+            if (pl.dyn > BIG_MAX_DYN_LDS || (cfg->threads_per_window != 0 && cfg->threads_per_window != pl.bv->NT)) pl.bv = nullptr;
         }
     }
-    if (!v && !bv) {
+    if (!pl.v && !pl.bv) {
         set_err("no kernel for K=%d max_T=%d threads_per_window=%d", cfg->K, maxT, cfg->threads_per_window);
         return HMCG_E_UNSUPPORTED;
     }
-    const int vNT = v ? v->NT : bv->NT, vL = v ? v->L : bigL, vK = cfg->K;
-    (void)vK;
+    *plan = pl;
+    return 0;
+}
+
+// Kernel parameters common to every launch of a call; per-launch fields (sweep range, resume, output window) are
+// filled by the caller.  All pointers are device pointers.
+hmcg::KernelParams base_params(const hmcg_config* cfg, int W, const double* dY, const int32_t* dT, const double* dyreal,
+                               int32_t* dstatus, const hmcg_extras* dex, bool use_sig)
+{
     hmcg::KernelParams p{};
+    const int n_samples = cfg->n_samples > 1 ? cfg->n_samples : 1;
     p.Y = dY; p.T = dT; p.yreal = dyreal;
-    p.ldY = cfg->ldY; p.W = cfg->W; p.H = cfg->H;
-    p.sweep_begin = cfg->sweep_base;
+    p.ldY = cfg->ldY; p.W = W; p.H = cfg->H;
     p.per_sample = cfg->burnin + cfg->nrun;
     p.burnin_s = cfg->burnin; p.nrun_s = cfg->nrun; p.n_samples = n_samples; p.nd = n_samples * cfg->nrun;
     if (p.per_sample < 1) p.per_sample = 1;
-    const int total_sweeps = n_samples * (cfg->burnin + cfg->nrun);
-    p.sweep_end = total_sweeps;
-    if (cfg->sweep_count > 0 && cfg->sweep_base + cfg->sweep_count < p.sweep_end) p.sweep_end = cfg->sweep_base + cfg->sweep_count;
-    p.resume = resume ? 1 : 0;
-    p.final_launch = (p.sweep_end == total_sweeps) ? 1 : 0;
     p.kappa = cfg->kappa;
-    if (ex) { p.pi_smooth_mean = ex->pi_smooth_mean; p.pi_filter_mean = ex->pi_filter_mean; }
-    if (ex) { p.sig_range = ex->sig_range; p.save_range = ex->save_range; p.sigma_signal = ex->sigma_signal; p.sigvals = ex->sigvals; p.nsave_ld = ex->nsave_ld; }
-    if (use_sig) { p.end_pos = ex->end_pos; p.blend_mask = cfg->blend_mask; }
     for (int h = 0; h < HMCG_MAXH; ++h) p.horizons[h] = h < cfg->H ? cfg->horizons[h] : 0;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.window_base = cfg->window_base;
     p.alpha = cfg->alpha > 0.0 ? cfg->alpha : 1.0;
     p.nu = cfg->nu > 0.0 ? cfg->nu : 1.0;
-    p.mu = dmu; p.sig2 = dsig2; p.A = dA; p.pi_end = dpi_end; p.fcast = dfcast; p.summary = dsummary;
     p.status = dstatus;
-    if (ex) { p.x_init = ex->x_init; p.x_final = ex->x_final; p.pif_final = ex->pif_final; p.xstate = ex->xstate; p.sumacc = ex->sumacc; p.window_ids = ex->window_ids; }
-    if (p.sweep_end < p.sweep_begin) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
-    if (p.sigvals && p.nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
+    if (dex) {
+        p.pi_smooth_mean = dex->pi_smooth_mean; p.pi_filter_mean = dex->pi_filter_mean;
+        p.sig_range = dex->sig_range; p.save_range = dex->save_range; p.sigma_signal = dex->sigma_signal;
+        p.sigvals = dex->sigvals; p.nsave_ld = dex->nsave_ld;
+        p.x_init = dex->x_init; p.x_final = dex->x_final; p.pif_final = dex->pif_final; p.xstate = dex->xstate;
+        p.sumacc = dex->sumacc; p.window_ids = dex->window_ids;
+        if (use_sig) { p.end_pos = dex->end_pos; p.blend_mask = cfg->blend_mask; }
+    }
+    return p;
+}
+
+void launch_kernel(const Plan& pl, const hmcg::KernelParams& p, hipStream_t stream)
+{
+    if (pl.v) hipLaunchKernelGGL(pl.v->fn, dim3((unsigned)p.W), dim3((unsigned)(pl.v->NT + 64 * pl.v->NH)), 0, stream, p);
+    else hipLaunchKernelGGL(pl.bv->fn, dim3((unsigned)p.W), dim3((unsigned)pl.bv->NT), pl.dyn, stream, p, pl.bigL);
+}
+
+void fill_timing(hmcg_timing* t, const Plan& pl, const DeviceCtx& c, double kernel_ms, int launches, double call_ms, int windows)
+{
+    if (!t) return;
+    t->kernel_ms = kernel_ms;
+    t->launches = launches;
+    t->threads_per_window = pl.NT();
+    t->steps_per_thread = pl.L();
+    t->helper_waves = pl.NH();
+    t->device = c.device;
+    t->call_ms = call_ms;
+    t->windows = windows;
+    t->reserved = 0;
+    t->lds_bytes = 0;
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, pl.fptr()) == hipSuccess) t->lds_bytes = (int32_t)(fa.sharedSizeBytes + pl.dyn);
+}
+
+#ifdef HMCG_STAMPS
+int print_stamps(const hmcg::KernelParams& p, const Plan& pl, unsigned long long* ddbg, size_t ndbg, hipStream_t stream)
+{
+    static const char* names[HMCG_NSTAMP] = {"Ba wait", "param draws | shadow jobs", "Bb wait", "theta+ux+pdfs", "local product",
+        "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats", "  (shadow: outputs)", "  (shadow: prep)", "  (stats: accumulate+N ballots)", "  (stats: wave sums)", "  (stats: pair ballots)", "unused"};
+    const int nwv = pl.NT() / 64 + pl.NH();
+    std::vector<unsigned long long> h(ndbg);
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const int nsw = p.sweep_end - p.sweep_begin;
+    fprintf(stderr, "[stamps] K=%d L=%d NT=%d W=%d sweeps=%d: mean cycles per sweep by wave (s_memtime ticks)\n",
+            pl.v ? pl.v->K : pl.bv->K, pl.L(), pl.NT(), p.W, nsw);
+    fprintf(stderr, "%-24s", "phase");
+    for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, "   wave%-2d", wv);
+    fprintf(stderr, "\n");
+    std::vector<double> tot(nwv, 0.0);
+    for (int i = 0; i < HMCG_NSTAMP; ++i) {
+        fprintf(stderr, "%-24s", names[i]);
+        for (int wv = 0; wv < nwv; ++wv) {
+            double acc = 0;
+            for (int w = 0; w < p.W; ++w) acc += (double)h[((size_t)w * nwv + wv) * HMCG_NSTAMP + i];
+            acc /= (double)p.W * (nsw > 0 ? nsw : 1);
+            tot[wv] += acc;
+            fprintf(stderr, " %8.0f", acc);
+        }
+        fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "%-24s", "total");
+    for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, " %8.0f", tot[wv]);
+    fprintf(stderr, "\n");
+    return 0;
+}
+#endif
+
+// ---- device-resident entry: one launch over caller-owned HBM buffers -----------------------------------------
+int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const int32_t* dT, const double* dyreal, double* dmu,
+                  double* dsig2, double* dA, double* dpi_end, double* dfcast, double* dsummary, int32_t* dstatus,
+                  const hmcg_extras* ex, hipStream_t stream, hmcg_timing* timing)
+{
+    if (!dY || !dT || !dstatus) { set_err("Y, T and status are required"); return HMCG_E_BADARG; }
+    Plan pl;
+    int rc = make_plan(cfg, ex, cfg->W, c.cu_count, &pl);
+    if (rc) return rc;
+    const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
+    hmcg::KernelParams p = base_params(cfg, cfg->W, dY, dT, dyreal, dstatus, ex, pl.use_sig);
+    const int total_sweeps = p.n_samples * (cfg->burnin + cfg->nrun);
+    p.sweep_begin = cfg->sweep_base;
+    p.sweep_end = total_sweeps;
+    if (cfg->sweep_count > 0 && cfg->sweep_base + cfg->sweep_count < p.sweep_end) p.sweep_end = cfg->sweep_base + cfg->sweep_count;
+    p.resume = resume ? 1 : 0;
+    p.final_launch = (p.sweep_end == total_sweeps) ? 1 : 0;
+    p.mu = dmu; p.sig2 = dsig2; p.A = dA; p.pi_end = dpi_end; p.fcast = dfcast; p.summary = dsummary;
+    p.nd_ld = p.nd; p.draw_off = 0;
 
     if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
-    if (bv) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bv->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    if (timing) HIP_TRY(hipEventRecord(g_ctx.ev0, stream));
+    if (pl.bv) HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
+    if (timing) HIP_TRY(hipEventRecord(c.ev0, stream));
 #ifdef HMCG_STAMPS
-    const int nwv = vNT / 64 + (v ? v->NH : 0);
-    const size_t ndbg = (size_t)cfg->W * nwv * HMCG_NSTAMP;
+    const size_t ndbg = (size_t)cfg->W * (pl.NT() / 64 + pl.NH()) * HMCG_NSTAMP;
     unsigned long long* ddbg = nullptr;
     HIP_TRY(hipMalloc((void**)&ddbg, ndbg * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(ddbg, 0, ndbg * sizeof(unsigned long long), stream));
     p.dbg = ddbg;
 #endif
-    if (v) hipLaunchKernelGGL(v->fn, dim3((unsigned)cfg->W), dim3((unsigned)(v->NT + 64 * v->NH)), 0, stream, p);
-    else hipLaunchKernelGGL(bv->fn, dim3((unsigned)cfg->W), dim3((unsigned)bv->NT), dyn, stream, p, bigL);
+    launch_kernel(pl, p, stream);
     HIP_TRY(hipGetLastError());
 #ifdef HMCG_STAMPS
-    {
-        static const char* names[HMCG_NSTAMP] = {"Ba wait", "param draws | shadow jobs", "Bb wait", "theta+ux+pdfs", "local product",
-            "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats", "  (shadow: outputs)", "  (shadow: prep)", "  (stats: accumulate+N ballots)", "  (stats: wave sums)", "  (stats: pair ballots)", "unused"};
-        std::vector<unsigned long long> h(ndbg);
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        (void)hipFree(ddbg);
-        const int nsw = p.sweep_end - p.sweep_begin;
-        fprintf(stderr, "[stamps] K=%d L=%d NT=%d W=%d sweeps=%d: mean cycles per sweep by wave (s_memtime ticks)\n", vK, vL, vNT, cfg->W, nsw);
-        fprintf(stderr, "%-24s", "phase");
-        for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, "   wave%-2d", wv);
-        fprintf(stderr, "\n");
-        std::vector<double> tot(nwv, 0.0);
-        for (int i = 0; i < HMCG_NSTAMP; ++i) {
-            fprintf(stderr, "%-24s", names[i]);
-            for (int wv = 0; wv < nwv; ++wv) {
-                double acc = 0;
-                for (int w = 0; w < cfg->W; ++w) acc += (double)h[((size_t)w * nwv + wv) * HMCG_NSTAMP + i];
-                acc /= (double)cfg->W * (nsw > 0 ? nsw : 1);
-                tot[wv] += acc;
-                fprintf(stderr, " %8.0f", acc);
-            }
-            fprintf(stderr, "\n");
-        }
-        fprintf(stderr, "%-24s", "total");
-        for (int wv = 0; wv < nwv; ++wv) fprintf(stderr, " %8.0f", tot[wv]);
-        fprintf(stderr, "\n");
-    }
+    rc = print_stamps(p, pl, ddbg, ndbg, stream);
+    (void)hipFree(ddbg);
+    if (rc) return rc;
 #endif
     if (timing) {
-        HIP_TRY(hipEventRecord(g_ctx.ev1, stream));
-        HIP_TRY(hipEventSynchronize(g_ctx.ev1));
+        HIP_TRY(hipEventRecord(c.ev1, stream));
+        HIP_TRY(hipEventSynchronize(c.ev1));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1));
-        timing->kernel_ms = ms;
-        timing->launches = 1;
-        timing->threads_per_window = vNT;
-        timing->steps_per_thread = vL;
-        timing->helper_waves = v ? v->NH : 0;
-        timing->reserved = 0;
-        hipFuncAttributes fa{};
-        const void* fptr = v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn);
-        if (hipFuncGetAttributes(&fa, fptr) == hipSuccess)
-            timing->lds_bytes = (int32_t)(fa.sharedSizeBytes + dyn);
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+        fill_timing(timing, pl, c, ms, 1, 0.0, cfg->W);
     }
     return 0;
 }
 
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return (int)hipMalloc((void**)&p, n * sizeof(T)); }
+// ---- host entry on one device --------------------------------------------------------------------------------
+
+// kept draws produced by the sweeps [0, g) of the sampling schedule (n_samples blocks of burnin + nrun sweeps)
+long long kept_before(long long g, int per, int burnin, int nrun)
+{
+    const long long smp = g / per, i = g - smp * per;
+    return smp * nrun + std::max(0LL, std::min((long long)nrun, i - burnin));
+}
+// global sweep index just after kept draw number d - 1 (d >= 1) has been produced
+long long sweep_after_kept(long long d, int per, int burnin, int nrun)
+{
+    const long long smp = (d - 1) / nrun, i = (d - 1) - smp * nrun;
+    return smp * per + burnin + i + 1;
+}
+
+struct Chunk { int s0, s1; long long d0, d1; };   // sweeps [s0, s1) produce the kept draws [d0, d1)
+
+// Chunks of the sweep range [sb, se): draw counts halve from chunk to chunk down to ~1/16 of the run (the last chunk's
+// copy-out is the only one not hidden behind sampling), never more than `cap` draws in a chunk.
+std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int nrun, long long cap, bool stream_draws)
+{
+    std::vector<Chunk> out;
+    const long long dB = kept_before(sb, per, burnin, nrun), dE = kept_before(se, per, burnin, nrun);
+    const long long nd = dE - dB;
+    if (!stream_draws || nd <= 0 || se <= sb) { out.push_back({sb, se, dB, dE}); return out; }
+    const long long floor_sz = std::max(16LL, nd / 16);
+    long long d = dB;
+    int s = sb;
+    while (d < dE) {
+        const long long rem = dE - d;
+        long long take = std::min(cap, std::max((rem + 1) / 2, floor_sz));
+        if (rem - take < floor_sz / 2) take = std::min(cap, rem);       // no crumbs
+        take = std::min(take, rem);
+        const long long d1 = d + take;
+        const int s1 = d1 == dE ? se : (int)sweep_after_kept(d1, per, burnin, nrun);
+        out.push_back({s, s1, d, d1});
+        d = d1; s = s1;
+    }
+    if (out.back().s1 != se) out.back().s1 = se;
+    return out;
+}
+
+struct HostArrays {
+    const double* Y; const int32_t* T; const double* yreal;
+    double* mu; double* sig2; double* A; double* pi_end; double* fcast; double* summary; int32_t* status;
+    const hmcg_extras* ex;
 };
+
+// Runs the n windows idx[0..n) (rows of the caller's arrays; idx == nullptr: rows 0..n-1) on device context c.
+// Caller holds c.mu and has made c.device current.
+int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx, int n, const HostArrays& h, hmcg_timing* timing)
+{
+    const auto t_call = std::chrono::steady_clock::now();
+    Plan pl;
+    int rc = make_plan(cfg, h.ex, n, c.cu_count, &pl);
+    if (rc) return rc;
+    if (!h.Y || !h.T) { set_err("Y and T are required"); return HMCG_E_BADARG; }
+    const hmcg_extras* ex = h.ex;
+    const size_t K = (size_t)cfg->K, ld = (size_t)cfg->ldY, H = (size_t)cfg->H, N = (size_t)n;
+    const int n_samples = cfg->n_samples > 1 ? cfg->n_samples : 1;
+    const long long nd_total = (long long)n_samples * cfg->nrun;       // kept draws per window over the whole run
+    const size_t NS = 3 * K + K * K + 2 * H;
+    const bool resume_in = (cfg->flags & HMCG_FLAG_RESUME) != 0;
+    auto row = [&](int i) -> size_t { return idx ? (size_t)idx[i] : (size_t)i; };
+
+    // per-draw output columns of one window, in the order they sit in a chunk buffer
+    struct Col { double* host; size_t ncol; size_t off; };
+    Col cols[5] = { {h.mu, K, 0}, {h.sig2, K, 0}, {h.A, K * K, 0}, {h.pi_end, K, 0}, {h.fcast, 2 * H, 0} };
+    size_t ncols = 0;
+    for (Col& cc : cols) { if (!cc.host || nd_total == 0) cc.ncol = 0; cc.off = ncols; ncols += cc.ncol; }
+    const bool stream_draws = ncols > 0;
+
+    const int total_sweeps = n_samples * (cfg->burnin + cfg->nrun);
+    int sb = cfg->sweep_base, se = total_sweeps;
+    if (cfg->sweep_count > 0 && sb + cfg->sweep_count < se) se = sb + cfg->sweep_count;
+    const int per = std::max(1, cfg->burnin + cfg->nrun);
+    // chunk capacity: the ring of RING chunk buffers stays within ~1 GiB of device memory (and as much pinned memory)
+    long long cap = nd_total > 0 ? nd_total : 1;
+    if (stream_draws) {
+        const long long budget = (1LL << 30) / RING / (long long)(8 * ncols * N);
+        cap = std::max(1LL, std::min(cap, budget));
+    }
+    if (const char* cenv = getenv("HMCG_CHUNK_DRAWS")) { const long long v = atoll(cenv); if (v > 0) cap = std::min(cap, v); }
+    const bool one_chunk_env = getenv("HMCG_NO_CHUNKS") != nullptr;           // diagnostics: one launch, as the device entry
+    std::vector<Chunk> chunks = plan_chunks(sb, se, per, cfg->burnin, cfg->nrun, one_chunk_env ? (1LL << 40) : cap, stream_draws && !one_chunk_env);
+    long long chunk_max = 0;
+    for (const Chunk& ch : chunks) chunk_max = std::max(chunk_max, ch.d1 - ch.d0);
+    const bool chunked = chunks.size() > 1;
+
+    // ---- layouts ----
+    Layout LD, LP;
+    const size_t o_dY = LD.add(8 * N * ld), o_dT = LD.add(4 * N), o_dst = LD.add(4 * N), o_dwid = LD.add(4 * N);
+    const size_t o_dyr = (h.yreal && H) ? LD.add(8 * N * H) : 0;
+    const size_t o_dsum = h.summary ? LD.add(8 * N * NS) : 0;
+    const size_t chunk_bytes = 8 * ncols * N * (size_t)chunk_max;
+    size_t o_dchunk[RING] = {}, o_pchunk[RING] = {};
+    const int nring = stream_draws ? (int)std::min<size_t>(RING, chunks.size()) : 0;
+    for (int r = 0; r < nring; ++r) o_dchunk[r] = LD.add(chunk_bytes);
+    const bool need_ckpt = chunked || resume_in || (ex && (ex->xstate || ex->sumacc)) || se < total_sweeps;
+    const size_t o_dxs = need_ckpt ? LD.add(N * ld) : 0, o_dacc = need_ckpt ? LD.add(8 * N * (NS + K)) : 0;
+    const bool want_xi = ex && ex->x_init, want_xf = ex && ex->x_final, want_pif = ex && ex->pif_final;
+    const bool want_sm = ex && ex->pi_smooth_mean, want_fm = ex && ex->pi_filter_mean;
+    const bool want_sv = ex && ex->sigvals && ex->nsave_ld > 0;
+    const size_t nsv = want_sv ? (size_t)n_samples * (size_t)ex->nsave_ld : 0;
+    const size_t o_dxi = want_xi ? LD.add(4 * N * ld) : 0, o_dxf = want_xf ? LD.add(4 * N * ld) : 0;
+    const size_t o_dpif = want_pif ? LD.add(8 * N * ld * K) : 0;
+    const size_t o_dsm = want_sm ? LD.add(8 * N * ld * K) : 0, o_dfm = want_fm ? LD.add(8 * N * ld * K) : 0;
+    const size_t o_dsr = (ex && ex->sig_range) ? LD.add(8 * N) : 0, o_dsvr = (ex && ex->save_range) ? LD.add(8 * N) : 0;
+    const size_t o_dep = (ex && ex->end_pos) ? LD.add(4 * N) : 0, o_dss = (ex && ex->sigma_signal) ? LD.add(8 * N) : 0;
+    const size_t o_dsv = want_sv ? LD.add(8 * N * nsv) : 0;
+    // pinned staging: inputs, small outputs, chunk ring, one-off big extras
+    const size_t o_pY = LP.add(8 * N * ld), o_pT = LP.add(4 * N), o_pst = LP.add(4 * N), o_pwid = LP.add(4 * N);
+    const size_t o_pyr = (h.yreal && H) ? LP.add(8 * N * H) : 0;
+    const size_t o_psum = h.summary ? LP.add(8 * N * NS) : 0;
+    for (int r = 0; r < nring; ++r) o_pchunk[r] = LP.add(chunk_bytes);
+    const size_t o_pxs = need_ckpt ? LP.add(N * ld) : 0, o_pacc = need_ckpt ? LP.add(8 * N * (NS + K)) : 0;
+    const size_t o_pxi = want_xi ? LP.add(4 * N * ld) : 0, o_pxf = want_xf ? LP.add(4 * N * ld) : 0;
+    const size_t o_ppif = want_pif ? LP.add(8 * N * ld * K) : 0;
+    const size_t o_psm = want_sm ? LP.add(8 * N * ld * K) : 0, o_pfm = want_fm ? LP.add(8 * N * ld * K) : 0;
+    const size_t o_psr = (ex && ex->sig_range) ? LP.add(8 * N) : 0, o_psvr = (ex && ex->save_range) ? LP.add(8 * N) : 0;
+    const size_t o_pep = (ex && ex->end_pos) ? LP.add(4 * N) : 0, o_pss = (ex && ex->sigma_signal) ? LP.add(8 * N) : 0;
+    const size_t o_psv = want_sv ? LP.add(8 * N * nsv) : 0;
+    if (c.dev.ensure(LD.total) || c.pin.ensure(LP.total)) {
+        set_err("workspace allocation failed (%zu B device, %zu B pinned)", LD.total, LP.total);
+        return HMCG_E_NOMEM;
+    }
+    char* D = c.dev.base;
+    char* P = c.pin.base;
+    hipStream_t s = c.stream;
+#define DP(T_, off) reinterpret_cast<T_*>(D + (off))
+#define PP(T_, off) reinterpret_cast<T_*>(P + (off))
+
+    // ---- pack the inputs (rows idx[i] of the caller's arrays) into pinned staging, one H2D each ----
+    for (int i = 0; i < n; ++i) {
+        const size_t g = row(i);
+        memcpy(PP(double, o_pY) + (size_t)i * ld, h.Y + g * ld, 8 * ld);
+        PP(int32_t, o_pT)[i] = h.T[g];
+        PP(uint32_t, o_pwid)[i] = (ex && ex->window_ids) ? ex->window_ids[g] : cfg->window_base + (uint32_t)g;
+        if (h.yreal && H) memcpy(PP(double, o_pyr) + (size_t)i * H, h.yreal + g * H, 8 * H);
+        if (resume_in) PP(int32_t, o_pst)[i] = h.status ? h.status[g] : 0;
+        if (want_xi) memcpy(PP(int32_t, o_pxi) + (size_t)i * ld, ex->x_init + g * ld, 4 * ld);
+        if (ex && ex->sig_range) { PP(int32_t, o_psr)[2 * i] = ex->sig_range[2 * g]; PP(int32_t, o_psr)[2 * i + 1] = ex->sig_range[2 * g + 1]; }
+        if (ex && ex->save_range) { PP(int32_t, o_psvr)[2 * i] = ex->save_range[2 * g]; PP(int32_t, o_psvr)[2 * i + 1] = ex->save_range[2 * g + 1]; }
+        if (ex && ex->end_pos) PP(int32_t, o_pep)[i] = ex->end_pos[g];
+        if (ex && ex->sigma_signal) PP(double, o_pss)[i] = ex->sigma_signal[g];
+        if (resume_in) {
+            memcpy(PP(uint8_t, o_pxs) + (size_t)i * ld, ex->xstate + g * ld, ld);
+            if (ex->sumacc) memcpy(PP(double, o_pacc) + (size_t)i * (NS + K), ex->sumacc + g * (NS + K), 8 * (NS + K));
+            if (want_sm) memcpy(PP(double, o_psm) + (size_t)i * ld * K, ex->pi_smooth_mean + g * ld * K, 8 * ld * K);
+            if (want_fm) memcpy(PP(double, o_pfm) + (size_t)i * ld * K, ex->pi_filter_mean + g * ld * K, 8 * ld * K);
+        }
+    }
+#define H2D(doff, poff, bytes) HIP_TRY(hipMemcpyAsync(D + (doff), P + (poff), (bytes), hipMemcpyHostToDevice, s))
+    H2D(o_dY, o_pY, 8 * N * ld);
+    H2D(o_dT, o_pT, 4 * N);
+    H2D(o_dwid, o_pwid, 4 * N);
+    if (h.yreal && H) H2D(o_dyr, o_pyr, 8 * N * H);
+    if (want_xi) H2D(o_dxi, o_pxi, 4 * N * ld);
+    if (ex && ex->sig_range) H2D(o_dsr, o_psr, 8 * N);
+    if (ex && ex->save_range) H2D(o_dsvr, o_psvr, 8 * N);
+    if (ex && ex->end_pos) H2D(o_dep, o_pep, 4 * N);
+    if (ex && ex->sigma_signal) H2D(o_dss, o_pss, 8 * N);
+    if (resume_in) {
+        H2D(o_dst, o_pst, 4 * N);
+        H2D(o_dxs, o_pxs, N * ld);
+        if (ex->sumacc) H2D(o_dacc, o_pacc, 8 * N * (NS + K)); else HIP_TRY(hipMemsetAsync(D + o_dacc, 0, 8 * N * (NS + K), s));
+        if (want_sm) H2D(o_dsm, o_psm, 8 * N * ld * K);
+        if (want_fm) H2D(o_dfm, o_pfm, 8 * N * ld * K);
+    } else {
+        HIP_TRY(hipMemsetAsync(D + o_dst, 0, 4 * N, s));
+        if (want_sm) HIP_TRY(hipMemsetAsync(D + o_dsm, 0, 8 * N * ld * K, s));
+        if (want_fm) HIP_TRY(hipMemsetAsync(D + o_dfm, 0, 8 * N * ld * K, s));
+    }
+#undef H2D
+    // outputs a skipped window never writes read as zero
+    if (h.summary) HIP_TRY(hipMemsetAsync(D + o_dsum, 0, 8 * N * NS, s));
+    if (want_xf) HIP_TRY(hipMemsetAsync(D + o_dxf, 0, 4 * N * ld, s));
+    if (want_pif) HIP_TRY(hipMemsetAsync(D + o_dpif, 0, 8 * N * ld * K, s));
+    if (want_sv) HIP_TRY(hipMemsetAsync(D + o_dsv, 0, 8 * N * nsv, s));
+
+    hmcg_extras dex{};
+    dex.struct_size = (int32_t)sizeof(hmcg_extras);
+    dex.window_ids = DP(uint32_t, o_dwid);
+    if (want_xi) dex.x_init = DP(int32_t, o_dxi);
+    if (want_xf) dex.x_final = DP(int32_t, o_dxf);
+    if (want_pif) dex.pif_final = DP(double, o_dpif);
+    if (need_ckpt) { dex.xstate = DP(uint8_t, o_dxs); dex.sumacc = DP(double, o_dacc); }
+    if (want_sm) dex.pi_smooth_mean = DP(double, o_dsm);
+    if (want_fm) dex.pi_filter_mean = DP(double, o_dfm);
+    if (ex && ex->sig_range) dex.sig_range = DP(int32_t, o_dsr);
+    if (ex && ex->save_range) dex.save_range = DP(int32_t, o_dsvr);
+    if (ex && ex->end_pos) dex.end_pos = DP(int32_t, o_dep);
+    if (ex && ex->sigma_signal) dex.sigma_signal = DP(double, o_dss);
+    if (want_sv) { dex.sigvals = DP(double, o_dsv); dex.nsave_ld = ex->nsave_ld; }
+
+    hmcg::KernelParams base = base_params(cfg, n, DP(double, o_dY), DP(int32_t, o_dT), (h.yreal && H) ? DP(double, o_dyr) : nullptr,
+                                          DP(int32_t, o_dst), &dex, pl.use_sig);
+    base.summary = h.summary ? DP(double, o_dsum) : nullptr;
+    if (pl.bv) HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
+
+    // ---- the chunk pipeline ----
+    // kernel c -> evk[c % RING] -> SDMA copy of its chunk buffer into pinned staging (copy stream) -> evc[c % RING]
+    // -> host scatter into the caller's arrays.  A chunk buffer is [array][window][column][draw] with the chunk's own
+    // draw count as leading dimension (one contiguous block: a plain 1-D copy, which the SDMA engines carry without
+    // touching the CUs -- a helped sweep kernel leaves no registers for a blit kernel to run beside it).  Kernel
+    // c + RING reuses both the device and the pinned buffer of chunk c: the host enqueues it only after it has waited
+    // for copy c and scattered chunk c.
+    const int nch = (int)chunks.size();
+    double kernel_ms = 0.0;
+    std::vector<hipEvent_t> tev;          // per-chunk timing events (created only when timing is requested)
+    if (timing) {
+        tev.resize((size_t)nch + 1);
+        for (auto& e : tev) HIP_TRY(hipEventCreate(&e));
+    }
+    auto scatter = [&](int cidx) {
+        const Chunk& ch = chunks[cidx];
+        const size_t ndc = (size_t)(ch.d1 - ch.d0);
+        const double* src = PP(double, o_pchunk[cidx % RING]);
+        for (int i = 0; i < n; ++i) {
+            const size_t g = row(i);
+            for (const Col& cc : cols) {
+                for (size_t q = 0; q < cc.ncol; ++q)
+                    memcpy(cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0,
+                           src + ndc * (cc.off * N + q + cc.ncol * (size_t)i), 8 * ndc);
+            }
+        }
+    };
+    int next_scatter = 0;
+    for (int cidx = 0; cidx < nch; ++cidx) {
+        const Chunk& ch = chunks[cidx];
+        const int slot = cidx % RING;
+        if (stream_draws && cidx >= RING) {
+            // free the ring slot: chunk cidx - RING must have left the device buffer and the pinned buffer
+            while (next_scatter <= cidx - RING) {
+                HIP_TRY(hipEventSynchronize(c.evc[next_scatter % RING]));
+                scatter(next_scatter);
+                ++next_scatter;
+            }
+        }
+        hmcg::KernelParams p = base;
+        p.sweep_begin = ch.s0; p.sweep_end = ch.s1;
+        p.resume = (resume_in || cidx > 0) ? 1 : 0;
+        p.final_launch = (ch.s1 == total_sweeps) ? 1 : 0;
+        const size_t ndc = (size_t)(ch.d1 - ch.d0);
+        p.nd_ld = (int32_t)std::max<size_t>(ndc, 1); p.draw_off = (int32_t)ch.d0;
+        if (stream_draws) {
+            double* cb = DP(double, o_dchunk[slot]);
+            p.mu = cols[0].ncol ? cb + ndc * cols[0].off * N : nullptr;
+            p.sig2 = cols[1].ncol ? cb + ndc * cols[1].off * N : nullptr;
+            p.A = cols[2].ncol ? cb + ndc * cols[2].off * N : nullptr;
+            p.pi_end = cols[3].ncol ? cb + ndc * cols[3].off * N : nullptr;
+            p.fcast = cols[4].ncol ? cb + ndc * cols[4].off * N : nullptr;
+            // a skipped window writes nothing: its block must read as zero
+            HIP_TRY(hipMemsetAsync(cb, 0, 8 * ncols * N * ndc, s));
+        }
+        if (timing) HIP_TRY(hipEventRecord(tev[(size_t)cidx], s));
+        launch_kernel(pl, p, s);
+        HIP_TRY(hipGetLastError());
+        if (stream_draws) {
+            HIP_TRY(hipEventRecord(c.evk[slot], s));
+            HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
+            if (ndc > 0)
+                HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, c.copy));
+            HIP_TRY(hipEventRecord(c.evc[slot], c.copy));
+        }
+    }
+    if (timing) HIP_TRY(hipEventRecord(tev[(size_t)nch], s));
+
+    // ---- small outputs and one-off extras: D2H on the compute stream (after the last kernel) ----
+#define D2H(poff, doff, bytes) HIP_TRY(hipMemcpyAsync(P + (poff), D + (doff), (bytes), hipMemcpyDeviceToHost, s))
+    D2H(o_pst, o_dst, 4 * N);
+    if (h.summary) D2H(o_psum, o_dsum, 8 * N * NS);
+    if (want_xf) D2H(o_pxf, o_dxf, 4 * N * ld);
+    if (want_pif) D2H(o_ppif, o_dpif, 8 * N * ld * K);
+    if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
+    if (want_fm) D2H(o_pfm, o_dfm, 8 * N * ld * K);
+    if (want_sv) D2H(o_psv, o_dsv, 8 * N * nsv);
+    if (ex && ex->xstate) D2H(o_pxs, o_dxs, N * ld);
+    if (ex && ex->sumacc) D2H(o_pacc, o_dacc, 8 * N * (NS + K));
+#undef D2H
+    // drain the chunk pipeline while those copies run
+    if (stream_draws) {
+        for (; next_scatter < nch; ++next_scatter) {
+            HIP_TRY(hipEventSynchronize(c.evc[next_scatter % RING]));
+            scatter(next_scatter);
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        const size_t g = row(i);
+        if (h.status) h.status[g] = PP(int32_t, o_pst)[i];
+        if (h.summary) memcpy(h.summary + g * NS, PP(double, o_psum) + (size_t)i * NS, 8 * NS);
+        if (want_xf) memcpy(ex->x_final + g * ld, PP(int32_t, o_pxf) + (size_t)i * ld, 4 * ld);
+        if (want_pif) memcpy(ex->pif_final + g * ld * K, PP(double, o_ppif) + (size_t)i * ld * K, 8 * ld * K);
+        if (want_sm) memcpy(ex->pi_smooth_mean + g * ld * K, PP(double, o_psm) + (size_t)i * ld * K, 8 * ld * K);
+        if (want_fm) memcpy(ex->pi_filter_mean + g * ld * K, PP(double, o_pfm) + (size_t)i * ld * K, 8 * ld * K);
+        if (want_sv) memcpy(ex->sigvals + g * nsv, PP(double, o_psv) + (size_t)i * nsv, 8 * nsv);
+        if (ex && ex->xstate) memcpy(ex->xstate + g * ld, PP(uint8_t, o_pxs) + (size_t)i * ld, ld);
+        if (ex && ex->sumacc) memcpy(ex->sumacc + g * (NS + K), PP(double, o_pacc) + (size_t)i * (NS + K), 8 * (NS + K));
+    }
+#undef DP
+#undef PP
+    if (timing) {
+        for (int cidx = 0; cidx < nch; ++cidx) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, tev[(size_t)cidx], tev[(size_t)cidx + 1]));
+            kernel_ms += ms;       // includes the chunk's memset and any wait for a ring slot
+        }
+        for (auto& e : tev) (void)hipEventDestroy(e);
+        const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        fill_timing(timing, pl, c, kernel_ms, nch, call_ms, n);
+    }
+    return 0;
+}
+
+// Static LPT partition (as hmc.jl_amd/shard.py partition_windows): windows by length, longest first (stable), each to
+// the lightest device that still has room under the count cap ceil(W / G).
+std::vector<std::vector<int32_t>> partition_windows(const int32_t* T, int W, int G)
+{
+    std::vector<int32_t> order((size_t)W);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return T[a] > T[b]; });
+    std::vector<long long> load((size_t)G, 0);
+    std::vector<int> count((size_t)G, 0);
+    std::vector<std::vector<int32_t>> parts((size_t)G);
+    const int cap = (W + G - 1) / G;
+    for (int32_t w : order) {
+        int best = -1;
+        for (int r = 0; r < G; ++r)
+            if (count[(size_t)r] < cap && (best < 0 || load[(size_t)r] < load[(size_t)best])) best = r;
+        parts[(size_t)best].push_back(w);
+        load[(size_t)best] += T[w];
+        ++count[(size_t)best];
+    }
+    for (auto& p : parts) std::sort(p.begin(), p.end());
+    return parts;
+}
 
 }  // namespace
 
@@ -274,14 +747,11 @@ const char* hmcg_last_error(void) { return g_err; }
 
 void hmcg_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ctx.stream) {
-        (void)hipStreamSynchronize(g_ctx.stream);
-        (void)hipStreamDestroy(g_ctx.stream);
-        (void)hipEventDestroy(g_ctx.ev0);
-        (void)hipEventDestroy(g_ctx.ev1);
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    for (DeviceCtx& c : g_ctx) {
+        std::lock_guard<std::mutex> lc(c.mu);
+        destroy_context(c);
     }
-    g_ctx = Context{};
 }
 
 int hmcg_estimate_batch_device(const hmcg_config* cfg, const double* dY, const int32_t* dT, const double* dyreal,
@@ -289,118 +759,80 @@ int hmcg_estimate_batch_device(const hmcg_config* cfg, const double* dY, const i
                                double* dsummary, int32_t* dstatus, const hmcg_extras* dextras, void* stream,
                                hmcg_timing* timing)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     g_err[0] = 0;
     int rc = validate(cfg);
     if (rc) return rc;
-    rc = ensure_context(cfg->device);
+    DeviceCtx* c = nullptr;
+    rc = get_context(cfg->device, &c);
     if (rc) return rc;
-    hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
-    return launch_device(cfg, dY, dT, dyreal, dmu, dsig2, dA, dpi_end, dfcast, dsummary, dstatus, dextras, s, timing);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return launch_device(*c, cfg, dY, dT, dyreal, dmu, dsig2, dA, dpi_end, dfcast, dsummary, dstatus, dextras, s, timing);
 }
 
 int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* T, const double* yreal, double* mu,
                         double* sig2, double* A, double* pi_end, double* fcast, double* summary, int32_t* status,
                         const hmcg_extras* extras, hmcg_timing* timing)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    g_err[0] = 0;
+    int rc = validate(cfg);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = get_context(cfg->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const HostArrays h{Y, T, yreal, mu, sig2, A, pi_end, fcast, summary, status, extras};
+    return run_host_on_device(*c, cfg, nullptr, cfg->W, h, timing);
+}
+
+int hmcg_estimate_batch_multi(const hmcg_config* cfg, int32_t n_devices, const int32_t* device_ids, const double* Y,
+                              const int32_t* T, const double* yreal, double* mu, double* sig2, double* A, double* pi_end,
+                              double* fcast, double* summary, int32_t* status, const hmcg_extras* extras, hmcg_timing* timing)
+{
     g_err[0] = 0;
     int rc = validate(cfg);
     if (rc) return rc;
     if (!Y || !T) { set_err("Y and T are required"); return HMCG_E_BADARG; }
-    rc = ensure_context(cfg->device);
-    if (rc) return rc;
-    const size_t W = (size_t)cfg->W, K = (size_t)cfg->K, ld = (size_t)cfg->ldY, H = (size_t)cfg->H;
-    const size_t nsmp = cfg->n_samples > 1 ? (size_t)cfg->n_samples : 1;
-    const size_t nrun = nsmp * (size_t)cfg->nrun;        // kept draws per window
-    const size_t NS = 3 * K + K * K + 2 * H;
-    hipStream_t s = g_ctx.stream;
-    DevBuf<double> dY, dyr, dmu, dsig, dA, dpe, dfc, dsum, dpif, dacc;
-    DevBuf<int32_t> dT, dst, dxi, dxf;
-    DevBuf<uint8_t> dxs;
-    DevBuf<uint32_t> dwid;
-    DevBuf<int32_t> dsr, dsv, dep;
-    DevBuf<double> dss, dsvals, dsm, dfm;
-#define ALLOC(buf, n) do { if ((buf).alloc(n) != 0) { set_err("hipMalloc of %zu elements failed", (size_t)(n)); return HMCG_E_NOMEM; } } while (0)
-    ALLOC(dY, W * ld); ALLOC(dT, W); ALLOC(dst, W);
-    HIP_TRY(hipMemcpyAsync(dY.p, Y, sizeof(double) * W * ld, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dT.p, T, sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
-    if (yreal && H) { ALLOC(dyr, W * H); HIP_TRY(hipMemcpyAsync(dyr.p, yreal, sizeof(double) * W * H, hipMemcpyHostToDevice, s)); }
-    // outputs start zeroed so that skipped windows (status HMCG_ST_NONFINITE / HMCG_ST_BAD_T) read as 0
-#define ALLOC0(buf, n) do { ALLOC(buf, n); HIP_TRY(hipMemsetAsync((buf).p, 0, sizeof(double) * (size_t)(n), s)); } while (0)
-    if (mu && nrun) ALLOC0(dmu, W * K * nrun);
-    if (sig2 && nrun) ALLOC0(dsig, W * K * nrun);
-    if (A && nrun) ALLOC0(dA, W * K * K * nrun);
-    if (pi_end && nrun) ALLOC0(dpe, W * K * nrun);
-    if (fcast && nrun && H) ALLOC0(dfc, W * 2 * H * nrun);
-    if (summary) ALLOC0(dsum, W * NS);
-#undef ALLOC0
-    hmcg_extras dex{};
-    dex.struct_size = (int32_t)sizeof(hmcg_extras);
-    const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
-    if (extras) {
-        if (extras->struct_size != (int32_t)sizeof(hmcg_extras)) { set_err("hmcg_extras.struct_size mismatch"); return HMCG_E_BADARG; }
-        if (extras->x_init) { ALLOC(dxi, W * ld); HIP_TRY(hipMemcpyAsync(dxi.p, extras->x_init, sizeof(int32_t) * W * ld, hipMemcpyHostToDevice, s)); dex.x_init = dxi.p; }
-        if (extras->x_final) { ALLOC(dxf, W * ld); HIP_TRY(hipMemsetAsync(dxf.p, 0, sizeof(int32_t) * W * ld, s)); dex.x_final = dxf.p; }
-        if (extras->pif_final) { ALLOC(dpif, W * ld * K); HIP_TRY(hipMemsetAsync(dpif.p, 0, sizeof(double) * W * ld * K, s)); dex.pif_final = dpif.p; }
-        if (extras->xstate) {
-            ALLOC(dxs, W * ld);
-            if (resume) HIP_TRY(hipMemcpyAsync(dxs.p, extras->xstate, W * ld, hipMemcpyHostToDevice, s));
-            else HIP_TRY(hipMemsetAsync(dxs.p, 0, W * ld, s));
-            dex.xstate = dxs.p;
+    if (n_devices < 1 || n_devices > HMCG_MAXDEV) { set_err("n_devices %d out of range (1..%d)", n_devices, HMCG_MAXDEV); return HMCG_E_BADARG; }
+    std::vector<int32_t> devs((size_t)n_devices);
+    for (int i = 0; i < n_devices; ++i) devs[(size_t)i] = device_ids ? device_ids[i] : i;
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)i] == devs[(size_t)j]) { set_err("device %d listed twice", devs[(size_t)i]); return HMCG_E_BADARG; }
+    const int G = std::min<int>(n_devices, cfg->W);                 // never more devices than windows
+    const auto parts = partition_windows(T, cfg->W, G);
+    const HostArrays h{Y, T, yreal, mu, sig2, A, pi_end, fcast, summary, status, extras};
+    std::vector<int> rcs((size_t)G, 0);
+    std::vector<std::string> errs((size_t)G);
+    if (timing) memset(timing, 0, sizeof(hmcg_timing) * (size_t)n_devices);
+    auto worker = [&](int r) {
+        g_err[0] = 0;
+        DeviceCtx* c = nullptr;
+        int rr = get_context(devs[(size_t)r], &c);
+        if (!rr) {
+            std::lock_guard<std::mutex> lk(c->mu);
+            hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess) { set_err("hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e)); rr = (int)e; }
+            else rr = run_host_on_device(*c, cfg, parts[(size_t)r].data(), (int)parts[(size_t)r].size(), h, timing ? timing + r : nullptr);
         }
-        if (extras->sig_range) { ALLOC(dsr, 2 * W); HIP_TRY(hipMemcpyAsync(dsr.p, extras->sig_range, sizeof(int32_t) * 2 * W, hipMemcpyHostToDevice, s)); dex.sig_range = dsr.p; }
-        if (extras->save_range) { ALLOC(dsv, 2 * W); HIP_TRY(hipMemcpyAsync(dsv.p, extras->save_range, sizeof(int32_t) * 2 * W, hipMemcpyHostToDevice, s)); dex.save_range = dsv.p; }
-        if (extras->end_pos) { ALLOC(dep, W); HIP_TRY(hipMemcpyAsync(dep.p, extras->end_pos, sizeof(int32_t) * W, hipMemcpyHostToDevice, s)); dex.end_pos = dep.p; }
-        if (extras->sigma_signal) { ALLOC(dss, W); HIP_TRY(hipMemcpyAsync(dss.p, extras->sigma_signal, sizeof(double) * W, hipMemcpyHostToDevice, s)); dex.sigma_signal = dss.p; }
-        if (extras->sigvals && extras->nsave_ld > 0) {
-            ALLOC(dsvals, W * nsmp * (size_t)extras->nsave_ld);
-            HIP_TRY(hipMemsetAsync(dsvals.p, 0, sizeof(double) * W * nsmp * (size_t)extras->nsave_ld, s));
-            dex.sigvals = dsvals.p; dex.nsave_ld = extras->nsave_ld;
-        }
-        if (extras->pi_smooth_mean) {
-            ALLOC(dsm, W * ld * K);
-            if (resume) HIP_TRY(hipMemcpyAsync(dsm.p, extras->pi_smooth_mean, sizeof(double) * W * ld * K, hipMemcpyHostToDevice, s));
-            else HIP_TRY(hipMemsetAsync(dsm.p, 0, sizeof(double) * W * ld * K, s));
-            dex.pi_smooth_mean = dsm.p;
-        }
-        if (extras->pi_filter_mean) {
-            ALLOC(dfm, W * ld * K);
-            if (resume) HIP_TRY(hipMemcpyAsync(dfm.p, extras->pi_filter_mean, sizeof(double) * W * ld * K, hipMemcpyHostToDevice, s));
-            else HIP_TRY(hipMemsetAsync(dfm.p, 0, sizeof(double) * W * ld * K, s));
-            dex.pi_filter_mean = dfm.p;
-        }
-        if (extras->window_ids) { ALLOC(dwid, W); HIP_TRY(hipMemcpyAsync(dwid.p, extras->window_ids, sizeof(uint32_t) * W, hipMemcpyHostToDevice, s)); dex.window_ids = dwid.p; }
-        if (extras->sumacc) {
-            ALLOC(dacc, W * (NS + K));
-            if (resume) HIP_TRY(hipMemcpyAsync(dacc.p, extras->sumacc, sizeof(double) * W * (NS + K), hipMemcpyHostToDevice, s));
-            dex.sumacc = dacc.p;
-        }
+        rcs[(size_t)r] = rr;
+        errs[(size_t)r] = g_err;           // thread-local message of this worker
+    };
+    if (G == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve((size_t)G);
+        for (int r = 0; r < G; ++r) th.emplace_back(worker, r);
+        for (auto& t : th) t.join();
     }
-    if (resume && status) HIP_TRY(hipMemcpyAsync(dst.p, status, sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
-    else if (resume) HIP_TRY(hipMemsetAsync(dst.p, 0, sizeof(int32_t) * W, s));
-#undef ALLOC
-    rc = launch_device(cfg, dY.p, dT.p, dyr.p, dmu.p, dsig.p, dA.p, dpe.p, dfc.p, dsum.p, dst.p, &dex, s, timing);
-    if (rc) return rc;
-#define D2H(dst_, src_, n) do { if ((dst_) && (src_)) HIP_TRY(hipMemcpyAsync((dst_), (src_), (n), hipMemcpyDeviceToHost, s)); } while (0)
-    D2H(mu, dmu.p, sizeof(double) * W * K * nrun);
-    D2H(sig2, dsig.p, sizeof(double) * W * K * nrun);
-    D2H(A, dA.p, sizeof(double) * W * K * K * nrun);
-    D2H(pi_end, dpe.p, sizeof(double) * W * K * nrun);
-    D2H(fcast, dfc.p, sizeof(double) * W * 2 * H * nrun);
-    D2H(summary, dsum.p, sizeof(double) * W * NS);
-    D2H(status, dst.p, sizeof(int32_t) * W);
-    if (extras) {
-        D2H(extras->sigvals, dsvals.p, sizeof(double) * W * nsmp * (size_t)(extras->nsave_ld > 0 ? extras->nsave_ld : 0));
-        D2H(extras->pi_smooth_mean, dsm.p, sizeof(double) * W * ld * K);
-        D2H(extras->pi_filter_mean, dfm.p, sizeof(double) * W * ld * K);
-        D2H(extras->x_final, dxf.p, sizeof(int32_t) * W * ld);
-        D2H(extras->pif_final, dpif.p, sizeof(double) * W * ld * K);
-        D2H(extras->xstate, dxs.p, W * ld);
-        D2H(extras->sumacc, dacc.p, sizeof(double) * W * (NS + K));
-    }
-#undef D2H
-    HIP_TRY(hipStreamSynchronize(s));
+    for (int r = 0; r < G; ++r)
+        if (rcs[(size_t)r]) {
+            set_err("device %d: %s", devs[(size_t)r], errs[(size_t)r].c_str());
+            return rcs[(size_t)r];
+        }
     return 0;
 }
 

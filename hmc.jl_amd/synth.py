@@ -47,6 +47,20 @@ def generate_window(T, K=3, seed=20240000, params=None):
     return Y, X
 
 
+def _generate_same_length(seeds, T, K, params=None):
+    """generate_window for many seeds at once (same length): identical values, vectorised over the windows."""
+    p = params or params_for(K)
+    A, mu, sig2 = p["A"], p["mu"], p["sig2"]
+    n = len(seeds)
+    U = np.stack([_uniforms(sd, 3 * T) for sd in seeds])          # (n, 3T)
+    cdf = np.cumsum(A, axis=1)
+    X = np.zeros((n, T), dtype=np.int64)
+    for t in range(1, T):
+        X[:, t] = np.minimum((cdf[X[:, t - 1]] <= U[:, t, None]).sum(axis=1), K - 1)   # searchsorted(..., side="right")
+    z = np.sqrt(-2.0 * np.log(1.0 - U[:, T:2 * T])) * np.cos(2.0 * np.pi * U[:, 2 * T:3 * T])
+    return mu[X] + np.sqrt(sig2[X]) * z
+
+
 def generate_panel(W, T, K=3, horizon_pad=12, window_base=0, ragged=None):
     """Panel for the benchmark configs: W windows of length T (+horizon_pad extra
     points per window, returned separately as the realised future values).
@@ -56,8 +70,12 @@ def generate_panel(W, T, K=3, horizon_pad=12, window_base=0, ragged=None):
     Y = np.zeros((W, T))
     fut = np.zeros((W, horizon_pad))
     Tw = np.full(W, T, dtype=np.int32) if ragged is None else np.asarray(ragged, dtype=np.int32)
-    for w in range(W):
-        y, _ = generate_window(int(Tw[w]) + horizon_pad, K, 20240000 + window_base + w)
-        Y[w, :Tw[w]] = y[:Tw[w]]
-        fut[w] = y[Tw[w]:Tw[w] + horizon_pad]
+    for length in np.unique(Tw):
+        ws = np.nonzero(Tw == length)[0]
+        if len(ws) == 1:
+            y = generate_window(int(length) + horizon_pad, K, 20240000 + window_base + int(ws[0]))[0][None, :]
+        else:
+            y = _generate_same_length([20240000 + window_base + int(w) for w in ws], int(length) + horizon_pad, K)
+        Y[ws, :length] = y[:, :length]
+        fut[ws] = y[:, length:length + horizon_pad]
     return Y, Tw, fut

@@ -27,7 +27,9 @@
  * = hipError_t of a failed HIP call.  Per-window numerical trouble is reported in
  * status[w] (HMCG_ST_* bits), never as a call failure.  The caller allocates and
  * owns every buffer; the library keeps no caller pointer after return.  The host
- * entry is blocking.  Calls are serialised by an internal mutex.  There is NO CPU
+ * entries are blocking.  The library keeps one lazily created context per device (streams, events,
+ * grow-only device and pinned-host workspaces; hmcg_shutdown releases them); calls on the SAME device are
+ * serialised by that context's mutex, calls on different devices run concurrently.  There is NO CPU
  * fallback: without a usable GPU every compute entry fails with HMCG_E_NODEVICE.
  *
  * Array layouts are the reference's Julia (column-major) layouts with the window
@@ -51,10 +53,11 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 102
+#define HMCG_VERSION 103
 #define HMCG_MAXH 8
 #define HMCG_MAXTAIL 32         /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
+#define HMCG_MAXDEV 16           /* devices one process may drive */
 
 /* API-misuse return codes */
 #define HMCG_E_BADARG   (-1)
@@ -145,12 +148,17 @@ typedef struct hmcg_extras {
 } hmcg_extras;
 
 typedef struct hmcg_timing {
-    double kernel_ms;        /* HIP-event time of the sweep kernel(s) on the launch stream */
-    int32_t launches;
+    double kernel_ms;        /* HIP-event time of the sweep kernel(s) on the launch stream (summed over the chunks of a call) */
+    int32_t launches;        /* kernel launches of this call: the host entries run a long chain in chunks whose per-draw
+                                outputs travel to the caller while the next chunk samples */
     int32_t threads_per_window;
     int32_t steps_per_thread;
     int32_t lds_bytes;
     int32_t helper_waves;    /* extra 64-thread waves per window that carry the draw-phase side jobs (0 or 4) */
+    int32_t device;          /* HIP device ordinal this record describes */
+    double call_ms;          /* host entries: wall time of the whole call on this device -- staging, H2D, kernels, D2H and the
+                                scatter into the caller's arrays (0 for the device entry) */
+    int32_t windows;         /* windows this device ran */
     int32_t reserved;
 } hmcg_timing;
 
@@ -159,9 +167,11 @@ int hmcg_device_count(void);          /* number of usable HIP devices (0 if none
 const char* hmcg_last_error(void);    /* thread-local, never NULL */
 void hmcg_shutdown(void);             /* releases the library's streams/workspaces */
 
-/* Host-buffer entry: copies Y/T/yreal to the device, runs, copies results back.
- * Any output pointer may be NULL (that output is not produced).  Outputs of skipped windows
- * (status HMCG_ST_NONFINITE / HMCG_ST_BAD_T) are zero here; the device entry leaves them untouched. */
+/* Host-buffer entry: stages Y/T/yreal through pinned memory to the device, runs the chain in a few chunks and
+ * streams each chunk's per-draw outputs back (SDMA copy into pinned staging, then into the caller's arrays)
+ * while the next chunk samples.  Any output pointer may be NULL (that output is not produced).  Outputs of
+ * skipped windows (status HMCG_ST_NONFINITE / HMCG_ST_BAD_T / HMCG_ST_BAD_RANGE) are zero here; the device entry
+ * leaves them untouched. */
 int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* T, const double* yreal,
                         double* mu, double* sig2, double* A, double* pi_end, double* fcast,
                         double* summary, int32_t* status, const hmcg_extras* extras, hmcg_timing* timing);
@@ -175,6 +185,21 @@ int hmcg_estimate_batch_device(const hmcg_config* cfg, const double* dY, const i
                                double* dmu, double* dsig2, double* dA, double* dpi_end, double* dfcast,
                                double* dsummary, int32_t* dstatus, const hmcg_extras* dextras,
                                void* stream, hmcg_timing* timing);
+
+/* Multi-device host entry: the same contract as hmcg_estimate_batch, with the W windows of the call partitioned over
+ * n_devices GPUs of this node -- what the reference does with one SLURM array task per end date
+ * (slurmscripts/base_estimation.sh:5,17: `--array=120-579`, one Julia process per window).  Windows are independent
+ * chains, so the data path has no collective: the library sorts the windows by length, deals them to the lightest
+ * device (count-balanced), runs one host thread + stream + workspace per device, keys every window's random numbers by
+ * its GLOBAL id (extras.window_ids[w], or cfg->window_base + w) -- so the result is bit-identical to the
+ * single-device call whatever the partition -- and each device's thread places its windows' blocks straight into the
+ * caller's arrays (the gather).  cfg->device is ignored; device_ids lists distinct HIP ordinals (NULL: 0..n_devices-1).
+ * timing, if not NULL, receives n_devices records.  Returns 0, an HMCG_E_* code, or the hipError_t of the first
+ * device that failed (hmcg_last_error() names it). */
+int hmcg_estimate_batch_multi(const hmcg_config* cfg, int32_t n_devices, const int32_t* device_ids,
+                              const double* Y, const int32_t* T, const double* yreal,
+                              double* mu, double* sig2, double* A, double* pi_end, double* fcast,
+                              double* summary, int32_t* status, const hmcg_extras* extras, hmcg_timing* timing);
 
 #ifdef __cplusplus
 }

@@ -73,3 +73,20 @@ def test_gather_single_process():
     blk = torch.arange(12, dtype=torch.float64).reshape(4, 3)
     out = shard.gather_blocks(blk, [3, 0, 2, 1], 4)
     assert torch.equal(out[3], blk[0]) and torch.equal(out[0], blk[1]) and torch.equal(out[1], blk[3])
+
+
+def test_bench_parent_spawns_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus 2` outside torchrun: the parent starts two fresh ranks (torch.distributed.run, rendezvous
+    on 127.0.0.1) and relays their outcome.  Without a GPU the ranks stop with bench.py's own message -- which proves
+    the spawn path ran end to end; the parent itself never imports torch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert "needs a GPU" in (r.stderr + r.stdout)
