@@ -494,6 +494,15 @@ __device__ __forceinline__ uint32_t map_compose(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ int map_apply(uint32_t m, int s) { return (int)((m >> (4 * s)) & 15u); }
 
+// Byte-per-entry state maps for K <= 4 (the register-resident kernel): entry s of map m is byte s.  Composition is ONE
+// instruction -- v_perm_b32 selects, for every byte of b (a state 0..3), that byte of a: (a o b)[s] = a[b[s]].
+// Unused high bytes carry the identity so that they stay valid selectors.
+constexpr uint32_t BMAP_IDENTITY = 0x03020100u;
+__device__ __forceinline__ uint32_t bmap_const(int v) { return (uint32_t)v * 0x01010101u; }
+__device__ __forceinline__ uint32_t bmap_compose(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(a, a, b); }
+__device__ __forceinline__ int bmap_apply(uint32_t m, int s) { return (int)((m >> (8 * s)) & 0xFFu); }
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_WAVE_SHL1 = 0x130;
+
 // Julia round(x; digits=5) (basicsave, src/Hmc.jl:719) = rint(x * 1e5) / 1e5 with a CORRECTLY ROUNDED quotient, as the
 // oracle and a host-side mean of the per-draw CSV cells compute it: reciprocal estimate q0 = fl(n * 1e-5), exact fp64
 // residual r = n - q0 * 1e5 (one FMA), correction q0 + r * 1e-5.  For |n| < 2^53 the corrected value is the correctly
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(NT + 64 * NH) __attribute__((amdgpu_waves_per_eu(OC
 void gibbs_sweeps_kernel(const KernelParams p)
 {
     static_assert(NH == 0 || (NH == 4 && NT == 256), "helper waves: 256 + 256 threads");
-    static_assert(K >= 2 && K <= 7, "small-K kernel: all parameter-draw roles fit one wave");
+    static_assert(K >= 2 && K <= 4, "small-K kernel: byte-per-entry state maps (v_perm_b32 composition)");
     static_assert(NT % 64 == 0 && NT >= 128, "at least two whole waves (wave 0 draws, the others work in its shadow)");
     constexpr int NW = NT / 64;
     constexpr int KK = K * K;
@@ -1747,7 +1756,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int s = 0; s < K; ++s) pfn_last[s] = sh.pfirst[(tid + 1 < NT) ? tid + 1 : tid][s];
         uint32_t gmap[L];
-        uint32_t G = map_identity<K>();
+        uint32_t G = BMAP_IDENTITY;
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
@@ -1771,37 +1780,46 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     const double c = gok ? cum[r] : ucum;
                     idx += (c <= thr) ? 1 : 0;
                 }
-                m |= (uint32_t)idx << (4 * s);
+                m |= (uint32_t)idx << (8 * s);
             }
-            m = (t == T - 1) ? map_const<K>(xlast) : (t > T - 1 ? map_identity<K>() : m);
+            if constexpr (K < 4) m |= BMAP_IDENTITY & (0xFFFFFFFFu << (8 * K));       // unused bytes: identity
+            m = (t == T - 1) ? bmap_const(xlast) : (t > T - 1 ? BMAP_IDENTITY : m);
             gmap[l] = m;
-            G = map_compose<K>(m, G);      // G = g_{t0+l} o (g_{t0+l+1} o ...)
+            G = bmap_compose(m, G);      // G = g_{t0+l} o (g_{t0+l+1} o ...)
         }
         STAMP(9);
-        // inclusive suffix scan over lanes: H_lane = G_lane o G_{lane+1} o ... o G_63
+        // inclusive suffix scan over lanes: H_lane = G_lane o G_{lane+1} o ... o G_63.  Inside a 16-lane row by DPP
+        // row_shl (a lane whose source lies beyond its row receives the identity); across the four rows through the
+        // row totals (first lane of each row), read as scalars.
         uint32_t Hm = G;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t O = __shfl_down(Hm, d, 64);
-            const uint32_t C = map_compose<K>(Hm, O);
-            Hm = (lane + d < 64) ? C : Hm;
+        Hm = bmap_compose(Hm, (uint32_t)dpp_i32<DPP_ROW_SHL1, 0xF>((int)BMAP_IDENTITY, (int)Hm));
+        Hm = bmap_compose(Hm, (uint32_t)dpp_i32<DPP_ROW_SHL2, 0xF>((int)BMAP_IDENTITY, (int)Hm));
+        Hm = bmap_compose(Hm, (uint32_t)dpp_i32<DPP_ROW_SHL4, 0xF>((int)BMAP_IDENTITY, (int)Hm));
+        Hm = bmap_compose(Hm, (uint32_t)dpp_i32<DPP_ROW_SHL8, 0xF>((int)BMAP_IDENTITY, (int)Hm));
+        {
+            const uint32_t R1 = (uint32_t)__builtin_amdgcn_readlane((int)Hm, 16);
+            const uint32_t R2 = (uint32_t)__builtin_amdgcn_readlane((int)Hm, 32);
+            const uint32_t R3 = (uint32_t)__builtin_amdgcn_readlane((int)Hm, 48);
+            const uint32_t S1 = bmap_compose(R2, R3), S0 = bmap_compose(R1, S1);
+            const int row = lane >> 4;
+            const uint32_t after = row == 0 ? S0 : (row == 1 ? S1 : (row == 2 ? R3 : BMAP_IDENTITY));
+            Hm = bmap_compose(Hm, after);
         }
         if (lane == 0) sh.wmap[wave] = Hm;
         STAMP(10);
         __syncthreads();                                                     // Be
         STAMP(11);
-        uint32_t Rw = map_identity<K>();
+        uint32_t Rw = BMAP_IDENTITY;
 #pragma unroll
-        for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? map_compose<K>(sh.wmap[ww], Rw) : Rw;
-        uint32_t Hx = __shfl_down(Hm, 1, 64);
-        if (lane == 63) Hx = map_identity<K>();
-        const uint32_t Sfx = map_compose<K>(Hx, Rw);   // everything after this thread's chunk
-        int sin = map_apply(Sfx, 0);                   // constant map below T-1: evaluate anywhere
+        for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? bmap_compose(sh.wmap[ww], Rw) : Rw;
+        const uint32_t Hx = (uint32_t)dpp_i32<DPP_WAVE_SHL1, 0xF>((int)BMAP_IDENTITY, (int)Hm);   // lane 63: identity
+        const uint32_t Sfx = bmap_compose(Hx, Rw);     // everything after this thread's chunk
+        int sin = bmap_apply(Sfx, 0);                  // constant map below T-1: evaluate anywhere
         xnext = sin;
         x_end = xlast;
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
-            if (t0 + l < T) { sin = map_apply(gmap[l], sin); x[l] = sin; }
+            if (t0 + l < T) { sin = bmap_apply(gmap[l], sin); x[l] = sin; }
         }
         // pivots for the next sweep's one-pass statistics: this sweep's state means (X labels are unsorted)
 #pragma unroll
