@@ -179,7 +179,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
             uint32_t r[4];
             g.block(site, elem, idx, r);
-            const double lg = log_fast(1.0 - u53(r[0], r[1]));
+            const double uraw = u53(r[0], r[1]);
+            const double lg = log_fast(1.0 - uraw);
             double val = lg;
             if (t_gx || t_z) val = sqrt_fast(-2.0 * lg) * cos2pi_fast(u53(r[2], r[3]));
             double rs = 0.0;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 if (t_rho) rb.rho[task] = -lg * (1.0 / rs);
                 else if (t_gx) rb.x[role][j] = val;
                 else if (t_z) rb.z[task - (K + 2 * NG)] = val;
-                else if (t_gl) rb.lu[role][j] = val;
+                else if (t_gl) { rb.lu[role][j] = val; rb.uu[role][j] = uraw; }
             }
         }
     };
@@ -437,8 +438,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                         const double a = shape < 1.0 ? shape + 1.0 : shape;
                         const double dd = a - 1.0 / 3.0;
                         const double cc = rcp_fast(3.0 * sqrt_fast(dd));
-                        val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0]);
-                        if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1]);
+                        val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0], rb.uu[role][0]);
+                        if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1], rb.uu[role][1]);
                         if (val < 0.0) {
                             int j = 2;
                             for (; j < GAMMA_MAX_ATTEMPTS && val < 0.0; ++j) {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                                 rng.block(site, elem, 2u * (uint32_t)j, r);
                                 const double xx = box_muller(r);
                                 rng.block(site, elem, 2u * (uint32_t)j + 1u, r);
-                                val = mt_try(dd, cc, xx, log_fast(1.0 - u53(r[0], r[1])));
+                                { const double u3 = u53(r[0], r[1]); val = mt_try(dd, cc, xx, log_fast(1.0 - u3), u3); }
                             }
                             if (val < 0.0) { val = dd; st |= HMCG_ST_GAMMA_CAP; }
                         }

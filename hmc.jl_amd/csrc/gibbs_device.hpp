@@ -215,12 +215,18 @@ __device__ __forceinline__ double box_muller(const uint32_t (&r)[4])
     return sqrt(-2.0 * log_fast(1.0 - u1)) * cos2pi_fast(u2);
 }
 
-// Marsaglia-Tsang acceptance for one attempt: returns the variate or a negative number.
-__device__ __forceinline__ double mt_try(double d, double c, double x, double logu)
+// Marsaglia-Tsang acceptance for one attempt: returns the variate or a negative number.  `u` is the uniform behind
+// logu = log(1 - u).  The squeeze 1 - u < 1 - 0.0331 x^4 implies the exact test (Marsaglia & Tsang 2000, step 3: for
+// d >= 1/3 the bound holds with room to spare), so it decides identically and skips the logarithm; the exact test runs
+// only when some active lane fails the squeeze (a wave-uniform branch, about one parameter phase in five).
+__device__ __forceinline__ double mt_try(double d, double c, double x, double logu, double u)
 {
     const double v1 = 1.0 + c * x;
     const double v = v1 * v1 * v1;
-    const bool ok = (v1 > 0.0) && (logu < 0.5 * x * x + d - d * v + d * log_fast(v1 > 0.0 ? v : 1.0));
+    const double x2 = x * x;
+    bool ok = (v1 > 0.0) && (u > 0.0331 * (x2 * x2));
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull)
+        ok = ok || ((v1 > 0.0) && (logu < 0.5 * x2 + d - d * v + d * log_fast(v1 > 0.0 ? v : 1.0)));
     return ok ? d * v : -1.0;
 }
 
@@ -266,6 +272,22 @@ __device__ __forceinline__ double dpp_f64(double old, double v)
 {
     const int lo = dpp_i32<CTRL, RMASK>(__double2loint(old), __double2loint(v));
     const int hi = dpp_i32<CTRL, RMASK>(__double2hiint(old), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// full-row-mask variant whose source-less lanes receive 0.0 (bound_ctrl zero fill: no `old` register to initialise)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_zero(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// ... and 1.0 (only the high word needs an `old`)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_one(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -406,7 +428,10 @@ __device__ __forceinline__ void scan_level(double (&Q)[K * K])
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
-        for (int s = 0; s < K; ++s) O[r * K + s] = dpp_f64<CTRL, RMASK>((r == s) ? 1.0 : 0.0, Q[r * K + s]);
+        for (int s = 0; s < K; ++s) {
+            if constexpr (RMASK == 0xF) O[r * K + s] = (r == s) ? dpp_f64_one<CTRL>(Q[r * K + s]) : dpp_f64_zero<CTRL>(Q[r * K + s]);
+            else O[r * K + s] = dpp_f64<CTRL, RMASK>((r == s) ? 1.0 : 0.0, Q[r * K + s]);
+        }
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
@@ -428,7 +453,10 @@ __device__ __forceinline__ void scan_level_rev(double (&Q)[K * K])
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
-        for (int s = 0; s < K; ++s) O[r * K + s] = dpp_f64<CTRL, RMASK>((r == s) ? 1.0 : 0.0, Q[r * K + s]);
+        for (int s = 0; s < K; ++s) {
+            if constexpr (RMASK == 0xF) O[r * K + s] = (r == s) ? dpp_f64_one<CTRL>(Q[r * K + s]) : dpp_f64_zero<CTRL>(Q[r * K + s]);
+            else O[r * K + s] = dpp_f64<CTRL, RMASK>((r == s) ? 1.0 : 0.0, Q[r * K + s]);
+        }
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
@@ -582,6 +610,7 @@ struct RngBuf {                   // state-independent parts of one sweep's para
     static constexpr int NG = K + K * K;      // gamma roles: sig2_i (K) then A_ij (K*K, row-major)
     double x[NG][2];              // Box-Muller normal of attempts 0,1
     double lu[NG][2];             // log(1-u) of attempts 0,1
+    double uu[NG][2];             // ... and u itself (Marsaglia-Tsang squeeze)
     double z[K];                  // normals for mu_i
     double rho[K];                // the complete rho ~ Dirichlet(1) draw
 };
@@ -891,7 +920,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
             }
             uint32_t r[4];
             g.block(site, elem, idx, r);
-            const double lg = log_fast(1.0 - u53(r[0], r[1]));
+            const double uraw = u53(r[0], r[1]);
+            const double lg = log_fast(1.0 - uraw);
             double val = lg;
             if (t_gx || t_z) val = sqrt_fast(-2.0 * lg) * cos2pi_fast(u53(r[2], r[3]));   // Box-Muller
             // rho ~ Dirichlet(ones(K)) (:350-356): K exponentials normalised in element order (lanes 0..K-1 of pass 0)
@@ -902,7 +932,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 if (t_rho) rb.rho[task] = -lg * (1.0 / rs);
                 else if (t_gx) rb.x[role][j] = val;
                 else if (t_z) rb.z[task - (K + 2 * NG)] = val;
-                else if (t_gl) rb.lu[role][j] = val;
+                else if (t_gl) { rb.lu[role][j] = val; rb.uu[role][j] = uraw; }
             }
         }
     };
@@ -932,39 +962,54 @@ void gibbs_sweeps_kernel(const KernelParams p)
     constexpr int FC_WAVE = NH > 0 ? NW + 2 : NW - 1;    // owns the 2H forecast lanes (== OUT_WAVE when NW == 2)
     constexpr int PREP_WAVE = NH > 0 ? NW + 1 : (NW - 1 >= 3 ? 2 : 1);   // prepares the next sweep's RNG parts
     const int NP = 3 * K + KK;
-    int orole = -1;
-    if (wave == OUT_WAVE && lane < NP) orole = lane;
-    if (wave == FC_WAVE && lane >= 64 - 2 * HMCG_MAXH && lane - (64 - 2 * HMCG_MAXH) < 2 * p.H) orole = NP + lane - (64 - 2 * HMCG_MAXH);
-    if (orole >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
-    // per-lane constants of the output role (decoded once per launch)
-    double* out_base = nullptr;           // element (d=0) of this lane's output column
-    int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0;
-    bool fc_blend = false;                // signal path: this horizon is a forecastsignal blend
-    double fc_yr = 0.0;
+    // output role of a lane: [0, 3K) mu | sig2 | pi_end by sorted position, [3K, NP) A(:) column-major, [NP, NP + 2H)
+    // forecast / forecast error per horizon; -1: none.  Decoded from the lane id on every call (a handful of integer
+    // instructions on a shadow / helper wave) rather than once per launch: per-lane constants that stay live across
+    // the whole sweep loop are what the register allocator spills and splits -- the copies it then places around the
+    // divergent blocks are where the backend fault of DESIGN.md section 5a strikes -- and they cost every variant
+    // ~10 registers.  The value handed to `ln` is laundered so that the decode cannot be hoisted back out of the loop.
+    auto role_of = [&](int ln) __attribute__((always_inline)) -> int {
+        int r = -1;
+        if (wave == OUT_WAVE && ln < NP) r = ln;
+        if (wave == FC_WAVE && ln >= 64 - 2 * HMCG_MAXH && ln - (64 - 2 * HMCG_MAXH) < 2 * p.H) r = NP + ln - (64 - 2 * HMCG_MAXH);
+        return r;
+    };
     {
-        const size_t nrun = (size_t)p.nd_ld;
-        if (orole >= 0 && orole < 3 * K) {
-            o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
-            double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
-            if (base) out_base = base + nrun * ((size_t)o_q + (size_t)K * w);
-        } else if (orole >= 3 * K && orole < NP) {
-            const int e = orole - 3 * K;                   // column-major: e = i + K*j (src/Hmc.jl:745)
-            o_which = 3; o_i = e % K; o_j = e / K;
-            if (p.A) out_base = p.A + nrun * ((size_t)e + (size_t)KK * w);
-        } else if (orole >= NP) {
-            const int e = orole - NP;                      // 2h + {0: forecast, 1: error}
-            o_which = 4 + (e & 1);
-            fc_h = p.horizons[e >> 1];
-            fc_blend = SIG && ((p.blend_mask >> (e >> 1)) & 1);
-            fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (e >> 1)] : __builtin_nan("");
-            if (p.fcast) out_base = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w);
-        }
+        const int orole0 = role_of(lane);
+        if (orole0 >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole0];
     }
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
     auto job_outputs = [&](int sw) __attribute__((always_inline)) {
         // (without the signal path a launch is one sample: no division needed to find the kept-draw index)
         const int d = SIG ? kept_index(p, sw) : (sw >= p.burnin_s ? sw - p.burnin_s : -1);
-        if (d < 0 || orole < 0) return;
+        if (d < 0) return;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int orole = role_of(ln);
+        if (orole < 0) return;
+        double* out_base = nullptr;           // element (d = draw_off) of this lane's output column
+        int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0;
+        bool fc_blend = false;                // signal path: this horizon is a forecastsignal blend
+        double fc_yr = 0.0;
+        {
+            const size_t nrun = (size_t)p.nd_ld;
+            if (orole < 3 * K) {
+                o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
+                double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
+                if (base) out_base = base + nrun * ((size_t)o_q + (size_t)K * w);
+            } else if (orole < NP) {
+                const int e = orole - 3 * K;                   // column-major: e = i + K*j (src/Hmc.jl:745)
+                o_which = 3; o_i = e % K; o_j = e / K;
+                if (p.A) out_base = p.A + nrun * ((size_t)e + (size_t)KK * w);
+            } else {
+                const int e = orole - NP;                      // 2h + {0: forecast, 1: error}
+                o_which = 4 + (e & 1);
+                fc_h = p.horizons[e >> 1];
+                fc_blend = SIG && ((p.blend_mask >> (e >> 1)) & 1);
+                fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (e >> 1)] : __builtin_nan("");     // consumed after the forecast: latency hidden
+                if (p.fcast) out_base = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w);
+            }
+        }
         const ThetaBuf<K>& th = sh.th[sw & 1];
         double val;
         if (o_which >= 4) {
@@ -1383,8 +1428,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     const double a = shape < 1.0 ? shape + 1.0 : shape;
                     const double dd = a - 1.0 / 3.0;
                     const double cc = rsqrt_fast(dd) * (1.0 / 3.0);               // 1 / (3 sqrt(d))
-                    val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0]);
-                    if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1]);
+                    val = mt_try(dd, cc, rb.x[role][0], rb.lu[role][0], rb.uu[role][0]);
+                    if (val < 0.0) val = mt_try(dd, cc, rb.x[role][1], rb.lu[role][1], rb.uu[role][1]);
                     if (val < 0.0) {
                         // third and later attempts (rare): inline Philox
                         int j = 2;
@@ -1393,7 +1438,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
                             rng.block(site, elem, 2u * (uint32_t)j, r);
                             const double xx = box_muller(r);
                             rng.block(site, elem, 2u * (uint32_t)j + 1u, r);
-                            val = mt_try(dd, cc, xx, log_fast(1.0 - u53(r[0], r[1])));
+                            const double u3 = u53(r[0], r[1]);
+                            val = mt_try(dd, cc, xx, log_fast(1.0 - u3), u3);
                         }
                         if (val < 0.0) { val = dd; st |= HMCG_ST_GAMMA_CAP; }
                     }
@@ -1479,6 +1525,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         for (int l = 0; l < L; ++l) ux[l] = sh.ux[t0 + l];
         // ---- forward filter (:371-440) as a scan of M_t = A diag(f_t) ----
         double f[L][K];
+        unsigned und = 0;                            // bit l: every pdf of step l underflowed
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             unsigned hm = 0;
@@ -1494,15 +1541,22 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 f[l][s] = exp_tab(-(z * z), sh.exptab) * cf;
                 hm = max(hm, (unsigned)__double2hiint(f[l][s]));
             }
-            if (hm < 0x01A56E1Fu) {                  // largest pdf < 1e-300 (high word of 1e-300 is 0x01A56E1F)
-                // every pdf underflowed: treat the observation as missing (f = 1) and flag the window
-                if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+            // exact power-of-two scaling of the step: largest pdf into [0.5,1)
+            const int e = 1022 - (int)(hm >> 20);
 #pragma unroll
-                for (int s = 0; s < K; ++s) f[l][s] = 1.0;
-            } else {
-                const int e = 1022 - (int)(hm >> 20);   // exact power-of-two scaling of the step: largest pdf into [0.5,1)
+            for (int s = 0; s < K; ++s) f[l][s] = ldexp(f[l][s], e);
+            und |= (hm < 0x01A56E1Fu) ? (1u << l) : 0u;     // largest pdf < 1e-300 (high word of 1e-300 is 0x01A56E1F)
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(und != 0u) != 0ull, 0)) {
+            // (rare, wave-uniform branch) every pdf of some step underflowed: treat the observation as missing (f = 1)
+            // and flag the window -- the reference would produce NaN and throw (src/Hmc.jl:435)
 #pragma unroll
-                for (int s = 0; s < K; ++s) f[l][s] = ldexp(f[l][s], e);
+            for (int l = 0; l < L; ++l) {
+                if ((und >> l) & 1u) {
+                    if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) f[l][s] = 1.0;
+                }
             }
         }
         if constexpr (SIG) {
@@ -1580,18 +1634,21 @@ void gibbs_sweeps_kernel(const KernelParams p)
         double av[K];
 #pragma unroll
         for (int s = 0; s < K; ++s) av[s] = rho[s];
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // scalar: the loops over other waves branch, not select
 #pragma unroll
         for (int ww = 0; ww < NW - 1; ++ww) {
-            double nv[K];
+            if (ww < wave_u) {
+                double nv[K];
 #pragma unroll
-            for (int s = 0; s < K; ++s) {
-                double acc = av[0] * sh.wtot[ww][s];
+                for (int s = 0; s < K; ++s) {
+                    double acc = av[0] * sh.wtot[ww][s];
 #pragma unroll
-                for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
-                nv[s] = acc;
+                    for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
+                    nv[s] = acc;
+                }
+#pragma unroll
+                for (int s = 0; s < K; ++s) av[s] = nv[s];
             }
-#pragma unroll
-            for (int s = 0; s < K; ++s) av[s] = (ww < wave) ? nv[s] : av[s];
         }
         {
             double nv[K];
@@ -1619,11 +1676,14 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 nv[s] = acc * f[l][s];
                 total += nv[s];
             }
-            if (!(total > 0.0)) {                   // not reachable with finite positive parameters; kept as a guard
-                if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(total > 0.0)) != 0ull, 0)) {
+                // not reachable with finite positive parameters; kept as a guard (wave-uniform branch, never taken)
+                if (!(total > 0.0)) {
+                    if (t0 + l < T) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
-                for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
-                total = 1.0;
+                    for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
+                    total = 1.0;
+                }
             }
             const double inv = rcp_fast(total);
 #pragma unroll
@@ -1811,7 +1871,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         STAMP(11);
         uint32_t Rw = BMAP_IDENTITY;
 #pragma unroll
-        for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? bmap_compose(sh.wmap[ww], Rw) : Rw;
+        for (int ww = NW - 1; ww >= 1; --ww) if (ww > wave_u) Rw = bmap_compose(sh.wmap[ww], Rw);
         const uint32_t Hx = (uint32_t)dpp_i32<DPP_WAVE_SHL1, 0xF>((int)BMAP_IDENTITY, (int)Hm);   // lane 63: identity
         const uint32_t Sfx = bmap_compose(Hx, Rw);     // everything after this thread's chunk
         int sin = bmap_apply(Sfx, 0);                  // constant map below T-1: evaluate anywhere
@@ -1869,10 +1929,13 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     for (int q = 0; q < K; ++q) p.pi_smooth_mean[((size_t)w * p.ldY + t0 + l) * K + q] = sm_acc[l][q] * sc;
         }
     }
-    if (orole >= 0) {
-        if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;
-        if (p.summary && p.final_launch)
-            p.summary[(size_t)w * NS + orole] = p.nd > 0 ? sum_acc / (double)p.nd : __builtin_nan("");
+    {
+        const int orole = role_of(lane);
+        if (orole >= 0) {
+            if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;
+            if (p.summary && p.final_launch)
+                p.summary[(size_t)w * NS + orole] = p.nd > 0 ? sum_acc / (double)p.nd : __builtin_nan("");
+        }
     }
     if (p.sumacc) {
 #pragma unroll

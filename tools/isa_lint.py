@@ -26,9 +26,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(os.path.dirname(HERE), "hmc.jl_amd", "csrc", "obj")
 
-# register-allocator traffic: AGPR copies, scratch spills/reloads, and plain VGPR->VGPR moves (live-range splits).  A
-# join block's first real instruction is the exec restore, so such an instruction ahead of it -- with nothing but
-# prologue-class instructions around it -- was put there by the allocator under the wrong exec mask.
+# register-allocator traffic: AGPR copies, scratch spills/reloads, and plain VGPR->VGPR moves (live-range splits / late
+# copies).  A join block's first real instruction is the exec restore, so such an instruction ahead of it -- with nothing
+# but prologue-class instructions around it -- was put there under the wrong exec mask.  Plain moves are included on
+# evidence: round 2 saw `v_mov_b32 v208, v137` in this position in gibbs<3,8,256,SIG,p2>, and that build wrote the
+# last draw of every output lane from lane 0's role (tests/test_gpu_variants.py caught it).  A build that trips the rule
+# on a harmless per-edge PHI copy has to be perturbed too -- the gate is deliberately conservative.
 VEC_SPILL = re.compile(r"^\s*(v_accvgpr_(write|read|mov)_b32\s|scratch_(store|load)\w*\s|buffer_(store|load)\w*\s|"
                        r"v_mov_b32_e32\s+v\d+,\s*v\d+\s*$|v_mov_b64_e32\s+v\[\d+:\d+\],\s*v\[\d+:\d+\]\s*$)")
 PROLOGUE_OK = re.compile(r"^\s*(s_|v_writelane_b32|v_readlane_b32)")
