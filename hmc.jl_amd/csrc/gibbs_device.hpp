@@ -745,7 +745,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         return;
     }
 
-    if (tid < EXPTAB_N) sh.exptab[tid] = exp2((double)tid * (1.0 / EXPTAB_N));     // correctly rounded enough (OCML exp2, < 1 ulp)
+    for (int i = tid; i < EXPTAB_N; i += NT + 64 * NH) sh.exptab[i] = exp2((double)i * (1.0 / EXPTAB_N));   // correctly rounded enough (OCML exp2, < 1 ulp)
     // ---- load the window's observations (once per launch) ----
     double y[L];
     int x[L];
