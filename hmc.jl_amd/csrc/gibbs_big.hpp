@@ -47,6 +47,7 @@ struct BigShared {
     double fcM[2][K * K];         // forecast scratch (cooperative matrix power on the forecast wave)
     double fcv[2][K];
     double fcval[HMCG_MAXH];
+    double exptab[EXPTAB_N];      // 2^(j/N): the table of exp_tab (gibbs_device.hpp)
 };
 
 template <int K, int NT>
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         return;
     }
 
+    for (int i = tid; i < EXPTAB_N; i += NT) sh.exptab[i] = exp2((double)i * (1.0 / EXPTAB_N));
     // ---- observations into LDS (coalesced), xi = mean(Y) (src/Hmc.jl:136) ----
     bool bad = false;
     double part = 0.0;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const double z = (yv - th.mu[s]) * th.isd[s];
-            fv[s] = exp_fast(-0.5 * (z * z)) * th.coef[s];
+            fv[s] = exp_tab(-0.5 * (z * z), sh.exptab) * th.coef[s];
             hm = max(hm, (unsigned)__double2hiint(fv[s]));
         }
         if (hm < 0x01A56E1Fu) {
@@ -492,12 +494,16 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         }
         __syncthreads();                                                     // Bb
         // ---- forward filter: local product of this thread's L matrices A diag(f_t) ----
-        double Q[KK], N[KK];
+        double Q[KK];
 #pragma unroll
         for (int r = 0; r < K; ++r)
 #pragma unroll
             for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
-        auto mstep = [&](const double (&in)[KK], double (&out)[KK], int l) {
+        double N[KK];
+        // Q <- Q * (A diag(f_t)): one column of A at a time from LDS (wave-uniform address: a broadcast read), all K rows
+        // against it -- K independent accumulation chains.  (An in-place, two-rows-at-a-time form that keeps a single
+        // matrix live was measured: it frees the AGPR copies but reads A four times as often and lost 9 % to the LDS pipe.)
+        auto mstep = [&](const double (&in)[KK], double (&out)[KK], int l) __attribute__((always_inline)) {
             asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
             double fv[K];
             pdfs(th, ylds[t0 + l], t0 + l < T, fv);
@@ -530,13 +536,13 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
         }
         scan_level_rowwise<K, DPP_ROW_SHR1, 0xF>(Q, N);
-        scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(N, Q);
         rescale_pow2<KK>(Q);
         scan_level_rowwise<K, DPP_ROW_SHR4, 0xF>(Q, N);
-        scan_level_rowwise<K, DPP_ROW_SHR8, 0xF>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_SHR8, 0xF>(N, Q);
         rescale_pow2<KK>(Q);
         scan_level_rowwise<K, DPP_ROW_BCAST15, 0xA>(Q, N);
-        scan_level_rowwise<K, DPP_ROW_BCAST31, 0xC>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_BCAST31, 0xC>(N, Q);
         rescale_pow2<KK>(Q);
         if (lane == 63) {
 #pragma unroll
@@ -547,8 +553,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         double av[K];
 #pragma unroll
         for (int s = 0; s < K; ++s) av[s] = th.rho[s];
-#pragma unroll
-        for (int ww = 0; ww < NW - 1; ++ww) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        for (int ww = 0; ww < wave_u; ++ww) {
             double nv[K];
 #pragma unroll
             for (int s = 0; s < K; ++s) {
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 nv[s] = acc;
             }
 #pragma unroll
-            for (int s = 0; s < K; ++s) av[s] = (ww < wave) ? nv[s] : av[s];
+            for (int s = 0; s < K; ++s) av[s] = nv[s];
         }
         {
             double nv[K];

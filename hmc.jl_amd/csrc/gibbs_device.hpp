@@ -470,15 +470,19 @@ __device__ __forceinline__ void scan_level_rev(double (&Q)[K * K])
     for (int i = 0; i < K * K; ++i) Q[i] = N[i];
 }
 
-// Same, for large K: one source row at a time (K doubles live instead of K*K)
+// Same, for large K: one source row at a time (K doubles live instead of K*K); the result goes to N (the caller
+// ping-pongs between two matrices from level to level instead of copying back)
 template <int K, int CTRL, int RMASK>
-__device__ __forceinline__ void scan_level_rowwise(double (&Q)[K * K], double (&N)[K * K])
+__device__ __forceinline__ void scan_level_rowwise(const double (&Q)[K * K], double (&N)[K * K])
 {
 #pragma unroll
     for (int r = 0; r < K; ++r) {
         double o[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) o[k] = dpp_f64<CTRL, RMASK>((r == k) ? 1.0 : 0.0, Q[r * K + k]);
+        for (int k = 0; k < K; ++k) {
+            if constexpr (RMASK == 0xF) o[k] = (r == k) ? dpp_f64_one<CTRL>(Q[r * K + k]) : dpp_f64_zero<CTRL>(Q[r * K + k]);
+            else o[k] = dpp_f64<CTRL, RMASK>((r == k) ? 1.0 : 0.0, Q[r * K + k]);
+        }
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             double acc = o[0] * Q[s];
@@ -487,8 +491,6 @@ __device__ __forceinline__ void scan_level_rowwise(double (&Q)[K * K], double (&
             N[r * K + s] = acc;
         }
     }
-#pragma unroll
-    for (int i = 0; i < K * K; ++i) Q[i] = N[i];
 }
 
 // 4-bit-per-entry state maps (K <= 8).  entry s of map m: (m >> 4s) & 15.
