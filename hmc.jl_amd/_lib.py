@@ -23,7 +23,8 @@ ST_SKIPPED = ST_NONFINITE | ST_BAD_T | ST_BAD_RANGE      # the window was not co
 
 HMCG_MAXTAIL = 32
 EXPORTS = ("hmcg_version", "hmcg_device_count", "hmcg_last_error", "hmcg_shutdown",
-           "hmcg_estimate_batch", "hmcg_estimate_batch_device", "hmcg_estimate_batch_multi")
+           "hmcg_estimate_batch", "hmcg_estimate_batch_device", "hmcg_estimate_batch_multi",
+           "hmcg_save_results_csv", "hmcg_write_table_csv", "hmcg_format_float")
 HMCG_MAXDEV = 16
 
 
@@ -109,6 +110,9 @@ def load():
         L.hmcg_estimate_batch.restype = C.c_int
         L.hmcg_estimate_batch_device.restype = C.c_int
         L.hmcg_estimate_batch_multi.restype = C.c_int
+        L.hmcg_save_results_csv.restype = C.c_int
+        L.hmcg_write_table_csv.restype = C.c_int
+        L.hmcg_format_float.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -269,3 +273,42 @@ def estimate_batch_device(cfg, dY, dT, dyreal, dmu, dsig2, dA, dpi_end, dfcast, 
                                       C.byref(tm) if timed else None)
     _check(rc)
     return tm
+
+
+def format_float(x):
+    """CSV.jl 0.5.16 text of one Float64 (hmcg_format_float)."""
+    buf = C.create_string_buffer(48)
+    n = load().hmcg_format_float(C.c_double(float(x)), buf)
+    return buf.raw[:n].decode()
+
+
+def save_results_csv(dir, dates, K, horizons, res, sigvals=None, nsave=0, legacy_trans_header=False, n_threads=0):
+    """hmcg_save_results_csv: the five per-window CSV files of saveresults (src/Hmc.jl:724-748) for every window of a
+    result dict of estimate_batch_host (C-ABI layouts), written by the library's native writer."""
+    W = len(dates)
+    H = len(horizons)
+    os.makedirs(dir, exist_ok=True)
+
+    def arr(name, shape):
+        a = res.get(name)
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == shape, (name, a.shape, shape)
+        return a
+    nd = next(res[k].shape[-1] for k in ("mu", "sig2", "pi_end", "A", "fcast") if res.get(k) is not None)
+    mu, sig2, pe = arr("mu", (W, K, nd)), arr("sig2", (W, K, nd)), arr("pi_end", (W, K, nd))
+    A, fc = arr("A", (W, K, K, nd)), arr("fcast", (W, 2 * H, nd))
+    dts = (C.c_char_p * W)(*[str(d).encode() for d in dates])
+    hz = (C.c_int32 * max(H, 1))(*[int(h) for h in horizons])
+    sv = None
+    n_samples = nsave_ld = 0
+    if sigvals is not None:
+        sv = np.ascontiguousarray(sigvals, dtype=np.float64)
+        _, n_samples, nsave_ld = sv.shape
+    rc = load().hmcg_save_results_csv(str(dir).encode(), C.c_int32(W), dts, C.c_int32(K), C.c_int32(H), hz, C.c_int64(nd),
+                                      _np_ptr(mu), _np_ptr(sig2), _np_ptr(pe), _np_ptr(A), _np_ptr(fc), _np_ptr(sv),
+                                      C.c_int32(n_samples), C.c_int32(nsave), C.c_int32(nsave_ld),
+                                      C.c_int32(1 if legacy_trans_header else 0), C.c_int32(n_threads))
+    if rc != 0:
+        raise HmcgError("hmcg_save_results_csv rc=%d (directory %s)" % (rc, dir))

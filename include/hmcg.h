@@ -201,6 +201,31 @@ int hmcg_estimate_batch_multi(const hmcg_config* cfg, int32_t n_devices, const i
                               double* mu, double* sig2, double* A, double* pi_end, double* fcast,
                               double* summary, int32_t* status, const hmcg_extras* extras, hmcg_timing* timing);
 
+/* ---- per-draw CSV output (host code, no GPU): basicsave / saveresults, src/Hmc.jl:707-748 ------------------------------
+ * The five per-window files `filtered_means_<date>.csv`, `filtered_variances_<date>.csv`, `filtered_state_probs_<date>.csv`,
+ * `filtered_trans_probs_<date>.csv`, `forecasts_<date>.csv` (:741-746), written straight from the draw arrays of the
+ * estimate entries above (window w's block of every array), byte for byte as upstream's CSV.jl 0.5.16 writes them: header
+ * `date[,signalid],state_1..K | trans_i_j (i fastest, :727) | forecast_h,forecast_error_h [,signal_1..]`, one row per kept
+ * draw, values round(x; digits=5) (:719), LF line ends, CSV.jl float text (shortest round-trip digits; integral values
+ * without a fraction; |x| < 1e-4 as <integer mantissa>e-<n>).  250 000 rows x 5 files per window in production
+ * (code/run_hmm.jl:103-104).  Any of mu/sig2/pi_end/A/fcast may be NULL (that file is not written).
+ * dates: W strings "yyyy-mm-dd" (the end date of each window, Hmc.enddate).  sigvals (signal path, [W][n_samples][nsave_ld])
+ * adds the `signalid` column (1-based sample number of the row) and the `signal_j` columns (:715-717).
+ * n_threads: windows are written in parallel (0 = one thread per hardware thread).  Returns 0 or HMCG_E_BADARG (bad
+ * arguments / a file could not be written). */
+#define HMCG_CSV_LEGACY_TRANS_HEADER 1 /* name the transition columns trans_<j>_<i> as the committed fixtures do
+                                          (code/deprecated/Hmc.jl_08072019bak:711); data order is unchanged */
+int hmcg_save_results_csv(const char* dir, int32_t W, const char* const* dates, int32_t K, int32_t H, const int32_t* horizons,
+                          int64_t nd, const double* mu, const double* sig2, const double* pi_end, const double* A,
+                          const double* fcast, const double* sigvals, int32_t n_samples, int32_t nsave, int32_t nsave_ld,
+                          int32_t flags, int32_t n_threads);
+/* One table: `date,<colnames>` with n rows from a column-major block (element (d, c) at data[d + ld*c]), rounded to
+ * `precision` digits (basicsave, :707-722). */
+int hmcg_write_table_csv(const char* path, const char* date, int32_t ncol, const char* const* colnames, const double* data,
+                         int64_t n, int64_t ld, int32_t precision);
+/* CSV.jl 0.5.16 text of one Float64 into buf (>= 48 bytes, NUL-terminated); returns its length. */
+int hmcg_format_float(double x, char* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,3 +198,16 @@ def test_runaggregate_layouts(tmp_path):
     assert lines[0].startswith("date,signalid_mean,state_1_mean") and lines[0].endswith("signal_1_std,signal_2_std")
     row = [float(v) for v in lines[1].split(",")[1:]]
     assert row[0] == 1.5 and abs(row[6] - np.std([1.0, 2.0], ddof=1)) < 1e-15
+
+
+def test_calcdispersion_last_digit_cases(tmp_path):
+    """The three dates of the noise-0.3 fixture on which `x ** 0.5` and `sqrt(x)` differ in the last printed digit of a
+    standard deviation (1992-10-01, 2009-09-01, 2015-07-01): with the correctly rounded square root calcdispersion
+    reproduces the reference's lines character for character -- as it does for all 456 / 456 / 459 lines of the three
+    committed dispersion files when run on the reference's full summary files (tools/check_dispersion_full.py)."""
+    import shutil
+    shutil.copy(os.path.join(GOLDEN, "signals_noise_0.3_allsignal_forecasts_summary_sqrtcases.csv"), tmp_path / "forecasts_summary.csv")
+    hmc.calcdispersion(str(tmp_path))
+    got = open(tmp_path / "forecasts_dispersion.csv").read()
+    want = open(os.path.join(GOLDEN, "signals_noise_0.3_allsignal_forecasts_dispersion_sqrtcases.csv")).read()
+    assert got == want
