@@ -206,6 +206,7 @@ def test_calcdispersion_last_digit_cases(tmp_path):
     reproduces the reference's lines character for character -- as it does for all 456 / 456 / 459 lines of the three
     committed dispersion files when run on the reference's full summary files (tools/check_dispersion_full.py)."""
     import shutil
+    GOLDEN = os.path.join(ROOT, "tests", "golden")
     shutil.copy(os.path.join(GOLDEN, "signals_noise_0.3_allsignal_forecasts_summary_sqrtcases.csv"), tmp_path / "forecasts_summary.csv")
     hmc.calcdispersion(str(tmp_path))
     got = open(tmp_path / "forecasts_dispersion.csv").read()
