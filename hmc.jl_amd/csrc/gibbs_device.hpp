@@ -1762,7 +1762,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 b[r] = acc;
             }
             rescale_pow2<K>(b);
-            const bool kept = sweep >= p.burnin_s;           // SMOOTH excludes the signal path: one sample
+            const bool kept = SIG ? kept_index(p, sweep) >= 0 : sweep >= p.burnin_s;
 #pragma unroll
             for (int l = L - 1; l >= 0; --l) {
                 if (t0 + l < T) {

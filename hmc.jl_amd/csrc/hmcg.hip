@@ -152,7 +152,7 @@ void destroy_context(DeviceCtx& c)
 
 using namespace hmcg_host;
 int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
-const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k4, &g_group_sig, &g_group_smooth };
+const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
 
 constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
@@ -231,7 +231,6 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     if (ex && ex->sigvals && ex->nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
     const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
     if ((use_sig || use_smooth) && cfg->K >= 5) { set_err("signal path and smoothed / filtered means: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
-    if (use_smooth && use_sig) { set_err("pi_smooth_mean / pi_filter_mean are not available on the signal path"); return HMCG_E_UNSUPPORTED; }
     if (cfg->sweep_base > n_samples * (cfg->burnin + cfg->nrun)) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).

@@ -89,7 +89,7 @@ def estimate_window(Y, K, burnin, nrun, horizons=(12,), yreal=None, seed=1234, w
 
 def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alpha=1.0, nu=1.0, sigma_signal=0.0,
                      save=(0, 0), horizons=(12,), yreal=None, seed=1234, window_id=0, x_init=None, end_pos=-1,
-                     blend_mask=0, want_filter_mean=False):
+                     blend_mask=0, want_filter_mean=False, want_smooth=False):
     """estimatesignals!'s sampling loop (src/Hmc.jl:868-914) for one window; with n_samples=1 and
     sigma_signal=0 it is the base estimatemodel run on a window that has a signal set.
     sig/save are 0-based half-open position ranges.  end_pos (0-based) selects the position whose smoothed
@@ -108,6 +108,7 @@ def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alp
     sv = np.zeros((n_samples, max(nsave, 1)))
     xf = np.empty(T, dtype=np.int32); pf = np.empty((T, K))
     fm = np.zeros((T, K)) if want_filter_mean else None
+    sm = np.empty((K, T, nd)) if want_smooth else None
     xi = None if x_init is None else np.ascontiguousarray(x_init, dtype=np.int32)
     st = C.c_int(0)
     rc = lib().hmco_estimate_window_ex(_p(Y), C.c_int(T), C.c_int(K), C.c_int(burnin), C.c_int(nrun),
@@ -116,13 +117,15 @@ def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alp
                                        C.c_double(alpha), C.c_double(nu), C.c_int(n_samples), C.c_double(sigma_signal),
                                        C.c_int(save[0]), C.c_int(save[1]), C.c_int(end_pos), C.c_int(blend_mask),
                                        _p(mu), _p(sig2), _p(A), _p(pe), _p(fc),
-                                       None, _p(summ), _p(sv), _p(xf, _ip), _p(pf), _p(fm), C.byref(st))
+                                       _p(sm), _p(summ), _p(sv), _p(xf, _ip), _p(pf), _p(fm), C.byref(st))
     if rc != 0:
         raise ValueError("hmco_estimate_window_ex rc=%d" % rc)
     out = dict(mu=mu.T.copy(), sig2=sig2.T.copy(), A=A.transpose(2, 1, 0).copy(), pi_end=pe.T.copy(),
                fcast=fc.T.copy(), summary=summ, sigvals=sv[:, :nsave], x_final=xf, pif_final=pf, status=st.value)
     if want_filter_mean:
         out["pi_filter_mean"] = fm               # (T, K) sorted labels, mean over the kept draws
+    if want_smooth:
+        out["pi_smooth"] = sm.transpose(2, 1, 0).copy()      # (nd, T, K)
     return out
 
 

@@ -134,3 +134,35 @@ def test_bad_signal_ranges_are_flagged_not_written(hmclib):
     alone = _lib.estimate_batch_host(Y[1:2], Tw[1:2], K, 1, nrun, (12,), fut[1:2, 11:12], window_ids=[1], sig_range=sig[1:2],
                                      save_range=save[1:2], sigma_signal=ssg[1:2], kappa=0.5, n_samples=ns)
     assert np.array_equal(alone["sigvals"][0], body[1]) and np.array_equal(alone["mu"][0], out["mu"][1])
+
+
+SIGSMOOTH = [(int(m.group(1)), int(m.group(2))) for m in
+             re.finditer(r"HMCG_V\((\d+),\s*(\d+),\s*256,\s*true,\s*true", open(os.path.join(CSRC, "variants_sigsmooth.hip")).read())]
+
+
+@pytest.mark.parametrize("K,L", SIGSMOOTH, ids=["K%d-L%d" % c for c in SIGSMOOTH])
+def test_smoothed_and_filtered_means_on_the_signal_path(hmclib, oracle, K, L):
+    """extras.pi_smooth_mean / pi_filter_mean together with extras.sig_range (SURVEY 8f rank 2 on the estimatesignals! path):
+    the draw average, over all noise samples, of the smoothed (backwardupdate_P!, src/Hmc.jl:442-457) and filtered
+    probabilities in sorted labels, against the oracle's literal Pb recursion run on the same noisy data."""
+    assert len(SIGSMOOTH) >= 9
+    Tmax = 256 * L - (1 if L > 1 else 0)
+    lens = [Tmax, max(256 * (L // 2) + 1 if L > 1 else 2, Tmax - 77)]
+    Y, Tw, fut = synth.generate_panel(2, Tmax, K, ragged=lens)
+    sig = np.stack([Tw - np.array([30, 1]), Tw], axis=1).astype(np.int32)
+    ssig = np.array([0.4, 0.9])
+    burnin, nrun, ns = 2, 4, 3
+    g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), fut[:, 11:12], want_state=True, sig_range=sig, save_range=sig,
+                                 sigma_signal=ssig, kappa=0.6, n_samples=ns, alpha=2.0, nu=2.0, want_smooth=True, want_filter_mean=True)
+    assert g["steps_per_thread"] == L and g["helper_waves"] == 0
+    for w in range(2):
+        T = int(Tw[w])
+        o = oracle.estimate_signals(Y[w, :T], K, burnin, nrun, ns, sig=tuple(sig[w]), kappa=0.6, alpha=2.0, nu=2.0,
+                                    sigma_signal=float(ssig[w]), save=tuple(sig[w]), yreal=fut[w, 11:12], window_id=w,
+                                    want_smooth=True, want_filter_mean=True)
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :T], o["x_final"])
+        assert close(g["mu"][w].T, o["mu"]) < TOL
+        assert np.max(np.abs(g["pi_smooth_mean"][w, :T] - o["pi_smooth"].mean(axis=0))) < TOL
+        assert np.max(np.abs(g["pi_filter_mean"][w, :T] - o["pi_filter_mean"])) < TOL
+        assert np.max(np.abs(g["pi_smooth_mean"][w, :T].sum(axis=1) - 1)) < 1e-12
