@@ -50,7 +50,12 @@ struct BigShared {
     double exptab[EXPTAB_N];      // 2^(j/N): the table of exp_tab (gibbs_device.hpp)
 };
 
-template <int K, int NT>
+// SM: additionally run the backward pass (backwardupdate_P!, src/Hmc.jl:442-457) on every kept sweep and accumulate the
+// smoothed and the filtered probabilities of every step (sorted labels) into p.pi_smooth_mean / p.pi_filter_mean -- the
+// large-K / long-window counterpart of the SMOOTH variants of gibbs_device.hpp.  The filtered probabilities of the
+// running sweep pass through p.pif_final (written by the forward replay, read back by the backward pass), the running
+// sums live in HBM (T x K doubles per window do not fit on the chip: this variant genuinely streams them).
+template <int K, int NT, bool SM = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
     static_assert(K >= 2 && K <= 8, "4-bit map entries: K <= 8 (K <= 4 normally runs on the register-resident kernel; this one\n"
@@ -521,7 +526,19 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 }
             }
         };
-        {
+        const bool kept_sweep = sweep >= p.burnin_s;              // one sample per launch on this path
+        const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr);
+        if constexpr (SM) {
+            for (int l = 0; l < L; ++l) {
+                if (t0 + l < T) {                                 // padded steps stay out of the products (identity)
+                    mstep(Q, N, l);
+#pragma unroll
+                    for (int i = 0; i < KK; ++i) Q[i] = N[i];
+                    if (l & 1) rescale_pow2<KK>(Q);
+                }
+            }
+            rescale_pow2<KK>(Q);
+        } else {
             int l = 0;
             for (; l + 1 < L; l += 2) {
                 mstep(Q, N, l);
@@ -535,6 +552,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 rescale_pow2<KK>(Q);
             }
         }
+        double Qloc[SM ? KK : 1];                                 // this thread's own chunk product, for the suffix scan
+        if constexpr (SM) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i) Qloc[i] = Q[i];
+        }
+        (void)Qloc;
         scan_level_rowwise<K, DPP_ROW_SHR1, 0xF>(Q, N);
         scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(N, Q);
         rescale_pow2<KK>(Q);
@@ -633,9 +656,97 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
                 sh.ulast = uxs[T - 1];
             }
-            if (last_sweep && p.pif_final && t < T) {
+            if ((last_sweep || do_smooth) && p.pif_final && t < T) {
 #pragma unroll
                 for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t) * K + s] = av[s];
+            }
+        }
+        if constexpr (SM) {
+            if (do_smooth) {
+                // ---- backwardupdate_P! as the beta recursion b_{t-1} = A (f_t o b_t), b_{T-1} = 1; pib[t,:] ~ pif[t,:] o b_t.
+                // b at the end of a thread's chunk = (product of the LATER chunks' matrices) * 1: within the wave an
+                // exclusive suffix scan of the chunk products (prefix scan on lane-reversed data, multiplication order
+                // flipped), then the later waves' totals -- the forward wave totals, already in LDS.
+                double bw[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) bw[r] = 1.0;
+                for (int ww = NW - 1; ww > wave_u; --ww) {
+                    double nb[K];
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c < K; ++c) acc = fma(sh.wtot[ww][r * K + c], bw[c], acc);
+                        nb[r] = acc;
+                    }
+                    rescale_pow2<K>(nb);
+#pragma unroll
+                    for (int r = 0; r < K; ++r) bw[r] = nb[r];
+                }
+                // lane-reversed copy, inclusive scan with the own matrix on the LEFT (column-wise DPP fetch of the source)
+                double R[KK], R2[KK];
+#pragma unroll
+                for (int i = 0; i < KK; ++i) R[i] = __shfl(Qloc[i], 63 - lane, 64);
+                scan_level_colwise<K, DPP_ROW_SHR1, 0xF>(R, R2);
+                scan_level_colwise<K, DPP_ROW_SHR2, 0xF>(R2, R);
+                rescale_pow2<KK>(R);
+                scan_level_colwise<K, DPP_ROW_SHR4, 0xF>(R, R2);
+                scan_level_colwise<K, DPP_ROW_SHR8, 0xF>(R2, R);
+                rescale_pow2<KK>(R);
+                scan_level_colwise<K, DPP_ROW_BCAST15, 0xA>(R, R2);
+                scan_level_colwise<K, DPP_ROW_BCAST31, 0xC>(R2, R);
+                rescale_pow2<KK>(R);
+                // exclusive suffix of lane j = inclusive result held by reversed lane (63-j)-1, i.e. physical lane 62-j
+                double b[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) {
+                        const double e = __shfl(R[r * K + c], lane < 63 ? 62 - lane : 0, 64);
+                        acc = fma((lane < 63) ? e : ((r == c) ? 1.0 : 0.0), bw[c], acc);
+                    }
+                    b[r] = acc;
+                }
+                rescale_pow2<K>(b);
+                double mu_s[K];
+                int order[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) mu_s[i] = th.mu[i];
+                sort_order<K>(mu_s, order);
+                for (int l = L - 1; l >= 0; --l) {
+                    asm volatile("" ::: "memory");
+                    const int t = t0 + l;
+                    if (t < T) {
+                        double g[K], pfv[K], tot = 0.0;
+                        const double* pft = p.pif_final + ((size_t)w * p.ldY + t) * K;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) { pfv[s] = pft[s]; g[s] = pfv[s] * b[s]; tot += g[s]; }
+                        const double inv = rcp_fast(tot);
+#pragma unroll
+                        for (int q = 0; q < K; ++q) {
+                            double gq = 0.0, fq = 0.0;
+#pragma unroll
+                            for (int s = 0; s < K; ++s) { gq = (order[q] == s) ? g[s] : gq; fq = (order[q] == s) ? pfv[s] : fq; }
+                            if (p.pi_smooth_mean) p.pi_smooth_mean[((size_t)w * p.ldY + t) * K + q] += gq * inv;   // sorted labels (:513)
+                            if (p.pi_filter_mean) p.pi_filter_mean[((size_t)w * p.ldY + t) * K + q] += fq;         // sorted pif[t,:] (:512)
+                        }
+                        double fv[K], fb[K], nb[K];
+                        pdfs(th, ylds[t], true, fv);
+#pragma unroll
+                        for (int s = 0; s < K; ++s) fb[s] = fv[s] * b[s];
+#pragma unroll
+                        for (int r = 0; r < K; ++r) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int s = 0; s < K; ++s) acc = fma(th.A[r][s], fb[s], acc);
+                            nb[r] = acc;
+                        }
+                        rescale_pow2<K>(nb);
+#pragma unroll
+                        for (int r = 0; r < K; ++r) b[r] = nb[r];
+                    }
+                }
             }
         }
         if (tid == NT - 1) maps[cap - 1] = map_identity<K>();
@@ -710,6 +821,21 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         if (p.summary && p.final_launch) p.summary[(size_t)w * NS + NP + fc_e] = p.nd > 0 ? sum_fc / (double)p.nd : __builtin_nan("");
     }
     if (p.sumacc && tid < K) p.sumacc[(size_t)w * NCK + NS + tid] = sh.pivot[tid];
+    if constexpr (SM) {
+        if (p.final_launch && p.nd > 0) {                        // running sums -> means (every thread its own steps)
+            const double sc = 1.0 / (double)p.nd;
+            for (int l = 0; l < L; ++l) {
+                const int t = t0 + l;
+                if (t < T) {
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        if (p.pi_smooth_mean) p.pi_smooth_mean[((size_t)w * p.ldY + t) * K + q] *= sc;
+                        if (p.pi_filter_mean) p.pi_filter_mean[((size_t)w * p.ldY + t) * K + q] *= sc;
+                    }
+                }
+            }
+        }
+    }
     if (st) atomicOr(&p.status[w], st);
 }
 

@@ -493,6 +493,28 @@ __device__ __forceinline__ void scan_level_rowwise(const double (&Q)[K * K], dou
     }
 }
 
+// The flipped order for large K: N = Q * (Q of the source lane), one source COLUMN at a time
+template <int K, int CTRL, int RMASK>
+__device__ __forceinline__ void scan_level_colwise(const double (&Q)[K * K], double (&N)[K * K])
+{
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        double o[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if constexpr (RMASK == 0xF) o[k] = (s == k) ? dpp_f64_one<CTRL>(Q[k * K + s]) : dpp_f64_zero<CTRL>(Q[k * K + s]);
+            else o[k] = dpp_f64<CTRL, RMASK>((s == k) ? 1.0 : 0.0, Q[k * K + s]);
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            double acc = Q[r * K] * o[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) acc = fma(Q[r * K + k], o[k], acc);
+            N[r * K + s] = acc;
+        }
+    }
+}
+
 // 4-bit-per-entry state maps (K <= 8).  entry s of map m: (m >> 4s) & 15.
 template <int K>
 __device__ __forceinline__ uint32_t map_identity()

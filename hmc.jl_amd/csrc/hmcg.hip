@@ -204,6 +204,7 @@ struct Plan {
     int bigL = 0;
     size_t dyn = 0;
     bool use_sig = false, use_smooth = false;
+    bool needs_pif() const { return bv != nullptr && use_smooth; }   // the LDS-resident smoothing kernel streams pif through pif_final
     int NT() const { return v ? v->NT : bv->NT; }
     int L() const { return v ? v->L : bigL; }
     int NH() const { return v ? v->NH : 0; }
@@ -230,7 +231,7 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     if (cfg->blend_mask < 0 || (cfg->H < 31 && (cfg->blend_mask >> cfg->H) != 0)) { set_err("blend_mask has bits beyond H"); return HMCG_E_BADARG; }
     if (ex && ex->sigvals && ex->nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
     const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
-    if ((use_sig || use_smooth) && cfg->K >= 5) { set_err("signal path and smoothed / filtered means: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
+    if (use_sig && cfg->K >= 5) { set_err("signal path: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     if (cfg->sweep_base > n_samples * (cfg->burnin + cfg->nrun)) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).
@@ -242,8 +243,10 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     Plan pl;
     pl.use_sig = use_sig; pl.use_smooth = use_smooth;
     if (cfg->K < 5) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
-    if (!pl.v && !use_sig && !use_smooth) {            // large K, or a window too long for the register-resident variants
-        for (int i = 0; i < g_n_big_variants; ++i) if (g_big_variants[i].K == cfg->K) pl.bv = &g_big_variants[i];
+    if (!pl.v && !use_sig) {                           // large K, or a window too long for the register-resident variants
+        const BigVariant* tab = use_smooth ? g_big_smooth_variants : g_big_variants;
+        const int ntab = use_smooth ? g_n_big_smooth_variants : g_n_big_variants;
+        for (int i = 0; i < ntab; ++i) if (tab[i].K == cfg->K) pl.bv = &tab[i];
         if (pl.bv) {
             pl.bigL = (maxT + pl.bv->NT - 1) / pl.bv->NT;
             pl.dyn = (size_t)pl.bv->NT * pl.bigL * (8 + 8 + 4 + 1) + 16;
@@ -353,6 +356,11 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
     Plan pl;
     int rc = make_plan(cfg, ex, cfg->W, c.cu_count, &pl);
     if (rc) return rc;
+    if (pl.needs_pif() && !(ex && ex->pif_final)) {
+        set_err("pi_smooth_mean / pi_filter_mean for K >= 5 or windows beyond the register-resident kernels need extras.pif_final "
+                "([W][ldY][K]: the running sweep's filtered probabilities pass through it)");
+        return HMCG_E_BADARG;
+    }
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
     hmcg::KernelParams p = base_params(cfg, cfg->W, dY, dT, dyreal, dstatus, ex, pl.use_sig);
     const int total_sweeps = p.n_samples * (cfg->burnin + cfg->nrun);
@@ -491,7 +499,8 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     for (int r = 0; r < nring; ++r) o_dchunk[r] = LD.add(chunk_bytes);
     const bool need_ckpt = chunked || resume_in || (ex && (ex->xstate || ex->sumacc)) || se < total_sweeps;
     const size_t o_dxs = need_ckpt ? LD.add(N * ld) : 0, o_dacc = need_ckpt ? LD.add(8 * N * (NS + K)) : 0;
-    const bool want_xi = ex && ex->x_init, want_xf = ex && ex->x_final, want_pif = ex && ex->pif_final;
+    const bool want_xi = ex && ex->x_init, want_xf = ex && ex->x_final;
+    const bool user_pif = ex && ex->pif_final, want_pif = user_pif || pl.needs_pif();     // scratch of the smoothing kernel
     const bool want_sm = ex && ex->pi_smooth_mean, want_fm = ex && ex->pi_filter_mean;
     const bool want_sv = ex && ex->sigvals && ex->nsave_ld > 0;
     const size_t nsv = want_sv ? (size_t)n_samples * (size_t)ex->nsave_ld : 0;
@@ -508,7 +517,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     for (int r = 0; r < nring; ++r) o_pchunk[r] = LP.add(chunk_bytes);
     const size_t o_pxs = need_ckpt ? LP.add(N * ld) : 0, o_pacc = need_ckpt ? LP.add(8 * N * (NS + K)) : 0;
     const size_t o_pxi = want_xi ? LP.add(4 * N * ld) : 0, o_pxf = want_xf ? LP.add(4 * N * ld) : 0;
-    const size_t o_ppif = want_pif ? LP.add(8 * N * ld * K) : 0;
+    const size_t o_ppif = user_pif ? LP.add(8 * N * ld * K) : 0;
     const size_t o_psm = want_sm ? LP.add(8 * N * ld * K) : 0, o_pfm = want_fm ? LP.add(8 * N * ld * K) : 0;
     const size_t o_psr = (ex && ex->sig_range) ? LP.add(8 * N) : 0, o_psvr = (ex && ex->save_range) ? LP.add(8 * N) : 0;
     const size_t o_pep = (ex && ex->end_pos) ? LP.add(4 * N) : 0, o_pss = (ex && ex->sigma_signal) ? LP.add(8 * N) : 0;
@@ -664,7 +673,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     D2H(o_pst, o_dst, 4 * N);
     if (h.summary) D2H(o_psum, o_dsum, 8 * N * NS);
     if (want_xf) D2H(o_pxf, o_dxf, 4 * N * ld);
-    if (want_pif) D2H(o_ppif, o_dpif, 8 * N * ld * K);
+    if (user_pif) D2H(o_ppif, o_dpif, 8 * N * ld * K);
     if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
     if (want_fm) D2H(o_pfm, o_dfm, 8 * N * ld * K);
     if (want_sv) D2H(o_psv, o_dsv, 8 * N * nsv);
@@ -684,7 +693,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (h.status) h.status[g] = PP(int32_t, o_pst)[i];
         if (h.summary) memcpy(h.summary + g * NS, PP(double, o_psum) + (size_t)i * NS, 8 * NS);
         if (want_xf) memcpy(ex->x_final + g * ld, PP(int32_t, o_pxf) + (size_t)i * ld, 4 * ld);
-        if (want_pif) memcpy(ex->pif_final + g * ld * K, PP(double, o_ppif) + (size_t)i * ld * K, 8 * ld * K);
+        if (user_pif) memcpy(ex->pif_final + g * ld * K, PP(double, o_ppif) + (size_t)i * ld * K, 8 * ld * K);
         if (want_sm) memcpy(ex->pi_smooth_mean + g * ld * K, PP(double, o_psm) + (size_t)i * ld * K, 8 * ld * K);
         if (want_fm) memcpy(ex->pi_filter_mean + g * ld * K, PP(double, o_pfm) + (size_t)i * ld * K, 8 * ld * K);
         if (want_sv) memcpy(ex->sigvals + g * nsv, PP(double, o_psv) + (size_t)i * nsv, 8 * nsv);

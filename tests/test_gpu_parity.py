@@ -175,19 +175,25 @@ def test_signal_path_signals_past_the_end_date(hmclib, oracle, K, T, sigLen):
     assert (bad["status"] == _lib.ST_BAD_T).all()
 
 
-@pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64, 5]), (2, [300, 2, 129]), (4, [700, 100, 3])])
+@pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64, 5]), (2, [300, 2, 129]), (4, [700, 100, 3]),
+                                    (5, [600, 65, 2, 300]), (8, [5000, 4999, 700]), (3, [5000, 4100]), (4, [1500, 1025])])
 def test_smoothed_probabilities_mean(hmclib, oracle, K, lens):
     """Optional output: the draw-average of the smoothed probabilities pib[:, t, :] (backwardupdate_P!,
     src/Hmc.jl:442-457, sorted labels :513).  The GPU runs the beta recursion as a suffix scan; the oracle
-    runs the reference's Pb recursion.  Same bar: 1e-9 on probabilities."""
+    runs the reference's Pb recursion.  Same bar: 1e-9 on probabilities.  K <= 4 within the register-resident range
+    runs the SMOOTH variants of gibbs_device.hpp; K >= 5 (incl. configs[3]'s 8 states, T = 5000) and longer windows run
+    the smoothing variant of the LDS-resident kernel, which streams the running sums through HBM."""
     Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
-    g = _lib.estimate_batch_host(Y, Tw, K, 3, 12, (12,), fut[:, 11:12], want_state=True, want_smooth=True)
+    nrun = 12 if max(lens) <= 1000 else 5
+    g = _lib.estimate_batch_host(Y, Tw, K, 3, nrun, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
     for w in range(len(lens)):
-        o = oracle.estimate_window(Y[w, :Tw[w]], K, 3, 12, (12,), fut[w, 11:12], window_id=w, want_smooth=True)
+        o = oracle.estimate_window(Y[w, :Tw[w]], K, 3, nrun, (12,), fut[w, 11:12], window_id=w, want_smooth=True)
         assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"])
         ref = o["pi_smooth"].mean(axis=0)                       # (T, K)
         got = g["pi_smooth_mean"][w, :Tw[w]]
         assert np.max(np.abs(got - ref)) < TOL, (w, np.max(np.abs(got - ref)))
+        assert np.max(np.abs(g["pi_filter_mean"][w, :Tw[w]].sum(axis=1) - 1)) < 1e-12
+        assert np.max(np.abs(g["pif_final"][w, :Tw[w]] - o["pif_final"])) < TOL
         assert np.max(np.abs(got.sum(axis=1) - 1)) < 1e-12
         assert np.max(np.abs(got[-1] - g["pi_end"][w].mean(axis=1))) < 1e-12       # pib[end,:] = pif[end,:] (:448)
         assert close(g["mu"][w].T, o["mu"]) < TOL

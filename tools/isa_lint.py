@@ -47,6 +47,7 @@ def lint_file(path):
     problems, table = [], []
     kernel = None
     in_prologue = False
+    last_getpc = -100
     pending = []            # vector spill instructions seen in the current block prologue
     with open(path) as f:
         lines = f.readlines()
@@ -65,7 +66,10 @@ def lint_file(path):
             continue
         if re.match(r"^\s*flat_", line):
             problems.append((path, n, kernel, "flat_* memory instruction", s))
-        if re.match(r"^\s*(s_swappc_b64|s_setpc_b64|s_call_b64)", line):
+        if re.match(r"^\s*s_getpc_b64", line):
+            last_getpc = n
+        if re.match(r"^\s*(s_swappc_b64|s_call_b64)", line) or (re.match(r"^\s*s_setpc_b64", line) and n - last_getpc > 6):
+            # (s_getpc + s_add + s_setpc within a few lines is branch relaxation -- a long jump in a very large kernel)
             problems.append((path, n, kernel, "function call / return (a device lambda was not inlined)", s))
         if in_prologue:
             if EXEC_WIDEN.match(line):
