@@ -118,33 +118,68 @@ def shape_record(name, K_, lens, draws, reps=3, device=0):
     return rec
 
 
-def end_to_end_record(Y, Tw, yreal, reps=5):
+def c_caller_record(Y, Tw, yreal, reps=20):
+    """The same workload from a plain-C caller (tests/cdriver, no Python in the process, buffers allocated once and reused --
+    what a Julia `ccall` site does): mean wall time per hmcg_estimate_batch call."""
+    import struct
+    import tempfile
+    import numpy as np
+    drv = os.path.join(ROOT, "tests", "cdriver", "hmcg_cdriver")
+    if not os.path.exists(drv):
+        return {"error": "tests/cdriver/hmcg_cdriver not built"}
+    W, ld = Y.shape
+    hd = [0x484d4347, 3, W, K, ld, 0, DRAWS, 1, HORIZON, 0, 0, 0, 0, 0, 0, 0, 0, 0, reps, 0]
+    with tempfile.TemporaryDirectory() as tmp:
+        req = os.path.join(tmp, "req.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<20i", *hd))
+            f.write(struct.pack("<3d", 0.0, 0.0, 0.0))
+            f.write(np.ascontiguousarray(Y, dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(Tw, dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(yreal, dtype="<f8").tobytes())
+        r = subprocess.run([drv, req, os.path.join(tmp, "resp.bin")], capture_output=True, text=True, timeout=300,
+                           env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
+    import re
+    m = re.search(r"cdriver bench: ([0-9.]+) ms per call.*?(\d+) launches, kernels ([0-9.]+) ms, call ([0-9.]+) ms", r.stdout)
+    if r.returncode != 0 or not m:
+        return {"error": (r.stdout + r.stderr)[-300:]}
+    ms = float(m.group(1))
+    return {"ms_per_call": ms, "value": W * DRAWS / (ms * 1e-3), "unit": "Gibbs draws/s", "launches": int(m.group(2)),
+            "kernel_ms_sum_timed_call": float(m.group(3)), "calls": reps}
+
+
+def end_to_end_record(Y, Tw, yreal, reps=7):
     """SURVEY.md 8(d)'s wall-clock definition on the headline shape: pageable host arrays in (H2D of the Y panel), every
     per-draw output back in the caller's pageable arrays (41 MB), through hmcg_estimate_batch."""
     import numpy as np
     from hmc_jl_amd import _lib
-    for _ in range(2):
-        r = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal)
-    t = []
+    out = None
+    for _ in range(3):
+        out = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal, out=out)
+    t, lib_ms = [], []
     for _ in range(reps):
         t0 = time.perf_counter()
-        r = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal)
+        out = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal, out=out)
         t.append(time.perf_counter() - t0)
+        lib_ms.append(out["call_ms"])
     ms = float(np.median(t)) * 1e3
+    r = out
     t2 = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        r2 = _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal, want_draws=False)
+        _lib.estimate_batch_host(Y, Tw, K, 0, DRAWS, (HORIZON,), yreal, want_draws=False)
         t2.append(time.perf_counter() - t0)
     ms2 = float(np.median(t2)) * 1e3
     nbytes = sum(r[k].nbytes for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "status"))
-    return {"workload": "configs[1] through the host entry: H2D of Y, %d chunked launches, D2H of all per-draw outputs "
-                        "(%.1f MB) into pageable caller arrays" % (r["launches"], nbytes / 1e6),
-            "ms_per_call": ms, "value": W_PER_GPU * DRAWS / (ms * 1e-3), "unit": "Gibbs draws/s",
-            "library_call_ms": r["call_ms"], "kernel_ms_sum": r["kernel_ms"], "launches": r["launches"],
-            "summary_only_ms_per_call": ms2, "summary_only_value": W_PER_GPU * DRAWS / (ms2 * 1e-3),
-            "note": "ms_per_call includes the Python wrapper's output allocation (np.zeros, 41 MB); library_call_ms is "
-                    "the wall time inside hmcg_estimate_batch"}
+    rec = {"workload": "configs[1] through the host entry: H2D of Y, %d chunked launches, D2H of all per-draw outputs "
+                       "(%.1f MB) into pageable caller arrays (reused from call to call)" % (r["launches"], nbytes / 1e6),
+           "ms_per_call": ms, "value": W_PER_GPU * DRAWS / (ms * 1e-3), "unit": "Gibbs draws/s",
+           "library_call_ms": float(np.median(lib_ms)), "kernel_ms_sum": r["kernel_ms"], "launches": r["launches"],
+           "summary_only_ms_per_call": ms2, "summary_only_value": W_PER_GPU * DRAWS / (ms2 * 1e-3),
+           "note": "ms_per_call is the Python caller's wall time (ctypes wrapper included); library_call_ms the wall time inside "
+                   "hmcg_estimate_batch; c_caller is the same call from tests/cdriver (plain C, no Python)"}
+    rec["c_caller"] = c_caller_record(Y, Tw, yreal)
+    return rec
 
 
 def spawn_ranks(args):

@@ -153,11 +153,13 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
-                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None):
+                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,).
-    devices: a list of HIP ordinals -> hmcg_estimate_batch_multi (windows partitioned over those GPUs)."""
+    devices: a list of HIP ordinals -> hmcg_estimate_batch_multi (windows partitioned over those GPUs).
+    out: a dict returned by an earlier call of the same shape -- its arrays are reused (a caller that owns its
+    buffers, as a Julia or C caller does, pays no allocation or first-touch page faults per call)."""
     L = load()
     Y = np.ascontiguousarray(Y, dtype=np.float64)
     W, ldY = Y.shape
@@ -165,14 +167,21 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     H = len(horizons)
     NS = 3 * K + K * K + 2 * H
     yr = None if yreal is None else np.ascontiguousarray(yreal, dtype=np.float64).reshape(W, H)
+    prev = out if out is not None else {}
     out = {}
     nd = max(int(n_samples), 1) * nrun          # kept draws per window (sample-major on the signal path)
     shapes = dict(mu=(W, K, nd), sig2=(W, K, nd), A=(W, K, K, nd), pi_end=(W, K, nd), fcast=(W, 2 * H, nd))
     keep = tuple(shapes) if want_draws is True else (tuple(want_draws) if want_draws else ())   # True, False or names
+
+    def buf(name, shape, dtype=np.float64):
+        a = prev.get(name)
+        return a if isinstance(a, np.ndarray) and a.shape == tuple(shape) and a.dtype == dtype and a.flags.c_contiguous else np.zeros(shape, dtype=dtype)
     for name in keep:
-        out[name] = np.zeros(shapes[name])
-    out["summary"] = np.zeros((W, NS))
-    out["status"] = np.zeros(W, dtype=np.int32)
+        out[name] = buf(name, shapes[name])
+    out["summary"] = buf("summary", (W, NS))
+    out["status"] = buf("status", (W,), np.int32)
+    if resume_state is None:
+        out["status"][:] = 0
     ex = Extras()
     ex.struct_size = C.sizeof(Extras)
     flags = 0

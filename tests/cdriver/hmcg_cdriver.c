@@ -4,14 +4,19 @@
  *   mode 0  hmcg_estimate_batch                     (estimatemodel, src/Hmc.jl:850-865)
  *   mode 1  hmcg_estimate_batch on the signal path  (estimatesignals!, src/Hmc.jl:868-914)
  *   mode 2  hmcg_estimate_batch_multi               (windows partitioned over the listed devices)
+ *   mode 3  timing loop over hmcg_estimate_batch with caller-owned, reused buffers (what a Julia caller does):
+ *           prints the mean wall time per call; bench.py reports it as the end-to-end figure of the C ABI
  * and writes the raw outputs for the pytest wrapper to compare with the oracle.
  * usage: hmcg_cdriver <request.bin> <response.bin> */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "hmcg.h"
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
 static int rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n ? 0 : -1; }
 static int wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n ? 0 : -1; }
@@ -62,6 +67,21 @@ int main(int argc, char** argv)
     if (hmcg_version() != HMCG_VERSION) { fprintf(stderr, "header/library version mismatch\n"); return 3; }
     if (hmcg_device_count() < 1) { fprintf(stderr, "no GPU: %s\n", hmcg_last_error()); return 4; }
     int rc;
+    if (mode == 3) {
+        const int reps = n_devices > 0 ? n_devices : 10;        /* (the header slot doubles as the repetition count) */
+        for (int i = 0; i < 3; ++i) {
+            rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, NULL);
+            if (rc) { fprintf(stderr, "libhmcgibbs rc=%d: %s\n", rc, hmcg_last_error()); return 5; }
+        }
+        const double t0 = now_ms();
+        for (int i = 0; i < reps; ++i) rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, NULL);
+        const double per = (now_ms() - t0) / reps;
+        rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, tm);
+        printf("cdriver bench: %.4f ms per call over %d calls (W=%d K=%d T<=%d draws=%d, all per-draw outputs to host); "
+               "timed call: %d launches, kernels %.3f ms, call %.3f ms\n", per, reps, W, K, ldY, nrun, tm[0].launches, tm[0].kernel_ms, tm[0].call_ms);
+        hmcg_shutdown();
+        return rc ? 5 : 0;
+    }
     if (mode == 2) {
         int32_t devs[HMCG_MAXDEV];
         for (int i = 0; i < n_devices; ++i) devs[i] = i;
