@@ -10,9 +10,11 @@
 # has a `julia` binary.  The tested host layer with the same surface is hmc.jl_amd/hmc.py; the C ABI
 # it shares with this file is what the parity tests exercise.
 #
-# Wired: estimatemodel, estimatewindows (batched), estimatesignals! (signal Monte-Carlo path incl. signals past the
-# end date), saveresults with and without signals.  Not wired here (available through the C ABI and the Python
-# host layer): explicit window ids, checkpoint/resume, the smoothed-probability output.  runaggregate /
+# Wired: estimatemodel, estimatewindows (batched; `devices = [0,1,...]` partitions the windows over several GPUs through
+# hmcg_estimate_batch_multi; `window_ids` pins the RNG streams), estimatesignals! (signal Monte-Carlo path incl. signals
+# past the end date), saveresults with and without signals -- written by the library's native CSV writer
+# (hmcg_save_results_csv: CSV.jl 0.5.16 float text, 250k rows x 5 files in under a second).  Not wired here (available
+# through the C ABI and the Python host layer): checkpoint/resume, the smoothed-probability output.  runaggregate /
 # calcdispersion of the reference work unchanged on the files written here (same names, columns and float text).
 #
 # Reference lines mirrored: estopt src/Hmc.jl:17-73, accessors :85-107, makedate :573-582,
@@ -73,6 +75,20 @@ struct hmcg_extras
     pi_filter_mean::Ptr{Float64}
 end
 const HMCG_MAXTAIL = 32
+const HMCG_MAXDEV = 16
+
+struct hmcg_timing                    # include/hmcg.h (ABI 103)
+    kernel_ms::Float64
+    launches::Int32
+    threads_per_window::Int32
+    steps_per_thread::Int32
+    lds_bytes::Int32
+    helper_waves::Int32
+    device::Int32
+    call_ms::Float64
+    windows::Int32
+    reserved::Int32
+end
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))
 device_count() = Int(ccall((:hmcg_device_count, LIBHMCG), Cint, ()))
@@ -141,13 +157,17 @@ end
 _yreal(opt::estopt) = [opt.endIndex + h <= length(opt.rawdata) ? opt.rawdata[opt.endIndex + h] : NaN for h in opt.horizons]
 
 """
-    estimatewindows(opts::Vector{estopt}; device=0, keepdraws=true, window_ids=nothing)
+    estimatewindows(opts::Vector{estopt}; device=0, devices=nothing, keepdraws=true, window_ids=nothing)
 
-One GPU call for many windows (all must share D, burnin, Nrun, horizons, seed).  Returns
+One call for many windows (all must share D, burnin, Nrun, horizons, seed) -- what the reference fans out as
+`sbatch --array=120-579`, one Julia process per end date (slurmscripts/base_estimation.sh:5,17).  `devices = [0, 1, ..., 7]`
+partitions the windows over those GPUs inside the library (hmcg_estimate_batch_multi: one host thread per device,
+results gathered into these arrays; bit-identical to the single-device call).  `window_ids` (UInt32 per window) pins
+the RNG streams.  Returns
 `(samples::Vector{NamedTuple}, summary::Matrix{Float64}, status::Vector{Int32})`; `summary[:, w]` holds the
 means of the 5-digit-rounded draws in the order mu | sigma | pib_end | A(:) | forecasts.
 """
-function estimatewindows(opts::Vector{estopt}; device::Integer=0, keepdraws::Bool=true, window_ids=nothing)
+function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothing, keepdraws::Bool=true, window_ids=nothing)
     foreach(_check_live, opts)
     o = opts[1]
     W = length(opts); K = o.D; H = length(o.horizons); nrun = o.Nrun
@@ -172,14 +192,24 @@ function estimatewindows(opts::Vector{estopt}; device::Integer=0, keepdraws::Boo
     summary = Array{Float64}(undef, NS, W)
     status = zeros(Int32, W)
     p(a) = isempty(a) ? Ptr{Float64}(C_NULL) : pointer(a)
-    # window_ids would travel in hmcg_extras; omitted here (window w uses RNG stream w)
-    window_ids === nothing || error("window_ids: pass through hmcg_extras (not wired in this host file yet)")
-    rc = GC.@preserve Y Ts yreal μ σ A πe fc summary status begin
-        ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
-              (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Cvoid}, Ptr{Cvoid}),
-              cfg, Y, Ts, H > 0 ? pointer(yreal) : Ptr{Float64}(C_NULL), p(μ), p(σ), p(A), p(πe), p(fc),
-              summary, status, C_NULL, C_NULL)
+    wids = window_ids === nothing ? UInt32[] : Vector{UInt32}(window_ids)
+    ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
+                         isempty(wids) ? Ptr{UInt32}(C_NULL) : pointer(wids), C_NULL, C_NULL, C_NULL, C_NULL, Int32(0), Int32(0),
+                         C_NULL, C_NULL, C_NULL))
+    yr = H > 0 ? pointer(yreal) : Ptr{Float64}(C_NULL)
+    rc = GC.@preserve Y Ts yreal μ σ A πe fc summary status wids begin
+        if devices === nothing
+            ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
+                  (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{hmcg_extras}, Ptr{Cvoid}),
+                  cfg, Y, Ts, yr, p(μ), p(σ), p(A), p(πe), p(fc), summary, status, ex, C_NULL)
+        else
+            devs = Vector{Int32}(devices)
+            ccall((:hmcg_estimate_batch_multi, LIBHMCG), Cint,
+                  (Ref{hmcg_config}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{hmcg_extras}, Ptr{Cvoid}),
+                  cfg, Int32(length(devs)), devs, Y, Ts, yr, p(μ), p(σ), p(A), p(πe), p(fc), summary, status, ex, C_NULL)
+        end
     end
     rc == 0 || error("libhmcgibbs rc=$rc: $(last_error())")
     samples = NamedTuple[]
@@ -267,11 +297,31 @@ function estimatesignals!(opt::estopt; device::Integer=0)
 end
 
 # ---- CSV output (layout of src/Hmc.jl:707-748) ---------------------------------------------
+# CSV.jl 0.5.16 float text (shortest round-trip digits; integral values without a fraction; |x| < 1e-4 as
+# <integer mantissa>e-<n>, e.g. 24e-11), produced by the library so that every host language prints the same bytes
 function _fmt(x::Float64)
-    isnan(x) && return "NaN"
-    x == trunc(x) && abs(x) < 1e15 && return string(Int64(x))
-    return repr(x)            # shortest round-trip digits; CSV.jl 0.5.16's integer-mantissa form for |x| < 1e-4
-                              # (e.g. 24e-11) is reproduced only by the Python host layer so far
+    buf = Vector{UInt8}(undef, 48)
+    n = ccall((:hmcg_format_float, LIBHMCG), Cint, (Float64, Ptr{UInt8}), x, buf)
+    return String(buf[1:n])
+end
+
+# The five per-window files of saveresults (:741-746) for draw arrays in Julia layout, through the library's writer
+# (hmcg_save_results_csv).  μ, σ, πe: (n, K); A: (n, K, K); fc: (n, 2H); sigvals: (nsave, noiseSamples) or nothing.
+function _save_native(dir, date, K, horizons, μ, σ, πe, A, fc; sigvals=nothing)
+    mkpath(dir)
+    H = length(horizons); n = size(μ, 1)
+    hz = Vector{Int32}(horizons)
+    dates = [string(date)]
+    sv = sigvals === nothing ? Ptr{Float64}(C_NULL) : pointer(sigvals)
+    nsmp = sigvals === nothing ? 0 : size(sigvals, 2); nsave = sigvals === nothing ? 0 : size(sigvals, 1)
+    rc = GC.@preserve μ σ πe A fc hz dates sigvals begin
+        ccall((:hmcg_save_results_csv, LIBHMCG), Cint,
+              (Cstring, Int32, Ptr{Cstring}, Int32, Int32, Ptr{Int32}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int32, Int32, Int32),
+              dir, Int32(1), dates, Int32(K), Int32(H), hz, Int64(n), μ, σ, πe, A, H > 0 ? pointer(fc) : Ptr{Float64}(C_NULL),
+              sv, Int32(nsmp), Int32(nsave), Int32(nsave), Int32(0), Int32(1))
+    end
+    rc == 0 || error("hmcg_save_results_csv rc=$rc (directory $dir)")
 end
 
 function basicsave(data, dates, fname, dataheader; precision=5, signal=Array{Float64}(undef, 0, 0), signalids=Int64[])
@@ -310,19 +360,9 @@ end
 
 function saveresults(samples, opt, dir; hassignals=false)
     hassignals && return _savesignalresults(samples, opt, dir)                     # :735-739 (writes under `dir`)
-    h1 = ["state_$i" for i in 1:opt.D]
-    h2 = vec(["trans_$(i)_$(j)" for i in 1:opt.D, j in 1:opt.D])
-    h3 = String[]
-    for h in opt.horizons
-        push!(h3, "forecast_$h"); push!(h3, "forecast_error_$h")
-    end
     odir = "data/output/$(opt.series)/"          # the reference ignores `dir` here (src/Hmc.jl:741)
-    mkpath(odir)
-    basicsave(samples.μ, samples.obsdates, odir * "filtered_means_$(enddate(opt)).csv", h1)
-    basicsave(samples.σ, samples.obsdates, odir * "filtered_variances_$(enddate(opt)).csv", h1)
-    basicsave(samples.πb[:, end, :], samples.obsdates, odir * "filtered_state_probs_$(enddate(opt)).csv", h1)
-    basicsave(reshape(samples.A, opt.Nrun, :), samples.obsdates, odir * "filtered_trans_probs_$(enddate(opt)).csv", h2)
-    basicsave(samples.forecasts, samples.obsdates, odir * "forecasts_$(enddate(opt)).csv", h3)
+    _save_native(odir, enddate(opt), opt.D, opt.horizons, samples.μ, samples.σ, samples.πb[:, end, :], samples.A,
+                 samples.forecasts)
 end
 
 end # module
