@@ -663,6 +663,10 @@ struct SweepShared {
     double med[2];
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
     double exptab[EXPTAB_N];      // 2^(j/N), j = 0..N-1
+    // decoded output role of every lane of the (at most two) output waves, staged once per launch: slot 0 = the
+    // parameter-output wave, slot 1 = the forecast wave when it is a different one
+    struct OutConst { double* base; double yr; int packed; int h; };
+    OutConst oc[2][64];
     // signal path with signals past the end date: the (scaled) emission values of the last `tail` steps, the
     // filtered probabilities at end_pos, and the current noise sample's last observation (by sample parity)
     double ftail[SIG ? HMCG_MAXTAIL : 1][K];
@@ -987,53 +991,59 @@ void gibbs_sweeps_kernel(const KernelParams p)
     constexpr int PREP_WAVE = NH > 0 ? NW + 1 : (NW - 1 >= 3 ? 2 : 1);   // prepares the next sweep's RNG parts
     const int NP = 3 * K + KK;
     // output role of a lane: [0, 3K) mu | sig2 | pi_end by sorted position, [3K, NP) A(:) column-major, [NP, NP + 2H)
-    // forecast / forecast error per horizon; -1: none.  Decoded from the lane id on every call (a handful of integer
-    // instructions on a shadow / helper wave) rather than once per launch: per-lane constants that stay live across
-    // the whole sweep loop are what the register allocator spills and splits -- the copies it then places around the
-    // divergent blocks are where the backend fault of DESIGN.md section 5a strikes -- and they cost every variant
-    // ~10 registers.  The value handed to `ln` is laundered so that the decode cannot be hoisted back out of the loop.
+    // forecast / forecast error per horizon; -1: none.  The role and what follows from it (output column pointer,
+    // horizon, realised value) are decoded ONCE per launch into LDS (sh.oc) and read back on every call: as per-lane
+    // registers they would stay live across the whole sweep loop in every wave -- the long-lived values the register
+    // allocator splits, with the copies it then places around divergent blocks being where the backend fault of
+    // DESIGN.md section 5a strikes (and ~10 registers on every variant); decoded afresh on every call they put ~40
+    // dependent integer instructions and two memory loads at the head of the forecast job, which bounds the parameter phase.
     auto role_of = [&](int ln) __attribute__((always_inline)) -> int {
         int r = -1;
         if (wave == OUT_WAVE && ln < NP) r = ln;
         if (wave == FC_WAVE && ln >= 64 - 2 * HMCG_MAXH && ln - (64 - 2 * HMCG_MAXH) < 2 * p.H) r = NP + ln - (64 - 2 * HMCG_MAXH);
         return r;
     };
-    {
-        const int orole0 = role_of(lane);
-        if (orole0 >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole0];
+    const int oslot = (wave == FC_WAVE && FC_WAVE != OUT_WAVE) ? 1 : 0;
+    if (wave == OUT_WAVE || wave == FC_WAVE) {
+        const int orole = role_of(lane);
+        double* out_base = nullptr;           // element (d = draw_off) of this lane's output column
+        int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0, fc_blend = 0;
+        double fc_yr = 0.0;
+        const size_t nrun = (size_t)p.nd_ld;
+        if (orole >= 0 && orole < 3 * K) {
+            o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
+            double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
+            if (base) out_base = base + nrun * ((size_t)o_q + (size_t)K * w);
+        } else if (orole >= 3 * K && orole < NP) {
+            const int e = orole - 3 * K;                   // column-major: e = i + K*j (src/Hmc.jl:745)
+            o_which = 3; o_i = e % K; o_j = e / K;
+            if (p.A) out_base = p.A + nrun * ((size_t)e + (size_t)KK * w);
+        } else if (orole >= NP) {
+            const int e = orole - NP;                      // 2h + {0: forecast, 1: error}
+            o_which = 4 + (e & 1);
+            fc_h = p.horizons[e >> 1];
+            fc_blend = (SIG && ((p.blend_mask >> (e >> 1)) & 1)) ? 1 : 0;
+            fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (e >> 1)] : __builtin_nan("");
+            if (p.fcast) out_base = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w);
+        }
+        typename Sh::OutConst c;
+        c.base = out_base; c.yr = fc_yr; c.h = fc_h;
+        c.packed = o_which | (o_q << 4) | (o_i << 8) | (o_j << 12) | (fc_blend << 16) | (orole >= 0 ? (1 << 30) : 0);
+        sh.oc[oslot][lane] = c;                            // (read back by the same lane only; the prologue's barriers follow)
+        if (orole >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
     }
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
     auto job_outputs = [&](int sw) __attribute__((always_inline)) {
         // (without the signal path a launch is one sample: no division needed to find the kept-draw index)
         const int d = SIG ? kept_index(p, sw) : (sw >= p.burnin_s ? sw - p.burnin_s : -1);
-        if (d < 0) return;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int orole = role_of(ln);
-        if (orole < 0) return;
-        double* out_base = nullptr;           // element (d = draw_off) of this lane's output column
-        int o_which = 0, o_q = 0, o_i = 0, o_j = 0, fc_h = 0;
-        bool fc_blend = false;                // signal path: this horizon is a forecastsignal blend
-        double fc_yr = 0.0;
-        {
-            const size_t nrun = (size_t)p.nd_ld;
-            if (orole < 3 * K) {
-                o_q = orole % K; o_which = orole / K;          // 0 mu, 1 sig2, 2 pi_end; sorted position q
-                double* base = o_which == 0 ? p.mu : (o_which == 1 ? p.sig2 : p.pi_end);
-                if (base) out_base = base + nrun * ((size_t)o_q + (size_t)K * w);
-            } else if (orole < NP) {
-                const int e = orole - 3 * K;                   // column-major: e = i + K*j (src/Hmc.jl:745)
-                o_which = 3; o_i = e % K; o_j = e / K;
-                if (p.A) out_base = p.A + nrun * ((size_t)e + (size_t)KK * w);
-            } else {
-                const int e = orole - NP;                      // 2h + {0: forecast, 1: error}
-                o_which = 4 + (e & 1);
-                fc_h = p.horizons[e >> 1];
-                fc_blend = SIG && ((p.blend_mask >> (e >> 1)) & 1);
-                fc_yr = p.yreal ? p.yreal[(size_t)w * p.H + (e >> 1)] : __builtin_nan("");     // consumed after the forecast: latency hidden
-                if (p.fcast) out_base = p.fcast + nrun * ((size_t)e + (size_t)(2 * p.H) * w);
-            }
-        }
+        if (d < 0 || !(wave == OUT_WAVE || wave == FC_WAVE)) return;
+        const typename Sh::OutConst c = sh.oc[oslot][lane];
+        if (!(c.packed >> 30)) return;
+        double* const out_base = c.base;
+        const int o_which = c.packed & 15, o_q = (c.packed >> 4) & 15, o_i = (c.packed >> 8) & 15, o_j = (c.packed >> 12) & 15;
+        const int fc_h = c.h;
+        const bool fc_blend = SIG && ((c.packed >> 16) & 1);       // signal path: this horizon is a forecastsignal blend
+        const double fc_yr = c.yr;
         const ThetaBuf<K>& th = sh.th[sw & 1];
         double val;
         if (o_which >= 4) {
@@ -1138,7 +1148,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 }
             }
         }
-        if (out_base) out_base[d - p.draw_off] = val;
+        // (the pointer came back from LDS as a generic one: say that it is global, or the store would be a flat_store)
+        if (out_base) ((__attribute__((address_space(1))) double*)out_base)[d - p.draw_off] = val;
         sum_acc += round5(val);
     };
 
@@ -1376,23 +1387,33 @@ void gibbs_sweeps_kernel(const KernelParams p)
         if (wave == 0) {
             // ---- parameter draws (sites 0,1,3; site 2 = rho comes ready-made from the shadow) ----
             const RngBuf<K>& rb = sh.rb[par];
-            const int role = lane;
-            const bool is_sig = role < K, is_g = role < NG;
+            // Lanes 0..K-1 draw sig2_i / mu_i; row i of A sits in its own quad, lanes 4+4i .. 4+4i+K-1 (K <= 4): the
+            // row sums (N_i, the Dirichlet normaliser) are then quad reductions by DPP instead of LDS shuffles.
+            const int qi = (lane - 4) >> 2, qj = (lane - 4) & 3;
+            const bool is_sig = lane < K, is_A = lane >= 4 && qi < K && qj < K;
+            const bool is_g = is_sig || is_A;
+            const int role = is_sig ? lane : (is_A ? K + qi * K + qj : NG);
             double shape = 1.0, bpar = 1.0, Neff = 0.0, Ssum = 0.0, rnn = 0.0;
             // transition count C_e of this lane's A role (e = role - K), summed over the waves' packed words
             int cT = 0;
             {
-                const int e = (role >= K && is_g) ? role - K : 0;
+                const int e = is_A ? role - K : 0;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) cT += (int)((sh.red_pk[ww][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                cT = is_A ? cT : 0;
             }
-            // N_i = sum_j C_ij + [X[T-1] == i]: row sums through the A lanes
+            // N_i = sum_j C_ij + [X[T-1] == i]: quad sums of the A lanes, handed to the sig2 lanes as scalars
             int rowsum = 0;
             {
-                const int i = is_sig ? role : 0;
+                int qs = cT + __builtin_amdgcn_mov_dpp(cT, 0xB1, 0xF, 0xF, false);        // quad_perm:[1,0,3,2]
+                qs += __builtin_amdgcn_mov_dpp(qs, 0x4E, 0xF, 0xF, false);                // quad_perm:[2,3,0,1]
 #pragma unroll
-                for (int j = 0; j < K; ++j) rowsum += __shfl(cT, K + i * K + j, 64);
+                for (int i = 0; i < K; ++i) {
+                    const int ri = __builtin_amdgcn_readlane(qs, 4 + 4 * i);
+                    rowsum = (lane == i) ? ri : rowsum;
+                }
             }
+            STAMP(16);
             if (is_g) {
                 const int c = is_sig ? rowsum + ((sh.x_end == role) ? 1 : 0) : cT;
                 if (is_sig) {
@@ -1439,6 +1460,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     shape = (double)(c + 1);                                     // :362-365
                 }
             }
+            STAMP(17);
             double val = 1.0;
             if (is_g) {
                 const uint32_t site = role < K ? SITE_SIG2 : SITE_A;
@@ -1474,11 +1496,12 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     }
                 }
             }
-            // normalise the Dirichlet rows of A: sum the row's variates in column order (:367)
-            const int gbase = (role >= K && is_g) ? K + ((role - K) / K) * K : K;
-            double gs = 0.0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) gs += __shfl(val, gbase + j, 64);
+            STAMP(18);
+            // normalise the Dirichlet rows of A (:367): quad sum of the row's variates ((v0 + v1) + (v2 + v3), absent
+            // columns contribute an exact 0: for K <= 3 this is the column-order sum)
+            double gs = is_A ? val : 0.0;
+            gs += quadperm_f64<0xB1>(gs);
+            gs += quadperm_f64<0x4E>(gs);
             if (is_sig) {
                 const double sig2 = bpar * rcp_fast(val);                        // :320 InverseGamma(a,b) = b / Gamma(a,1)
                 const double m = (Ssum + p.nu * xi) * rnn;                       // :331
@@ -1488,9 +1511,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 th.mu[role] = mu; th.sig2[role] = sig2;
                 th.isd[role] = isd * 0.70710678118654752440; th.coef[role] = INVSQRT2PI * isd;
                 th.rho[role] = rb.rho[role];                                     // :355
-            } else if (is_g) {
-                const int e = role - K;
-                th.A[e / K][e % K] = val * rcp_fast(gs);
+            } else if (is_A) {
+                th.A[qi][qj] = val * rcp_fast(gs);
             }
         } else {
             // ---- shadow of the parameter draws ----

@@ -317,7 +317,7 @@ void fill_timing(hmcg_timing* t, const Plan& pl, const DeviceCtx& c, double kern
 int print_stamps(const hmcg::KernelParams& p, const Plan& pl, unsigned long long* ddbg, size_t ndbg, hipStream_t stream)
 {
     static const char* names[HMCG_NSTAMP] = {"Ba wait", "param draws | shadow jobs", "Bb wait", "theta+ux+pdfs", "local product",
-        "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats", "  (shadow: outputs)", "  (shadow: prep)", "  (stats: accumulate+N ballots)", "  (stats: wave sums)", "  (stats: pair ballots)", "unused"};
+        "wave scan", "Bc wait", "prefix+replay+last", "Bd wait", "maps+compose", "map scan", "Be wait", "apply", "publish stats", "  (shadow: outputs)", "  (shadow: prep)", "  (param: counts+row sums)", "  (param: shapes)", "  (param: gamma)", "unused"};
     const int nwv = pl.NT() / 64 + pl.NH();
     std::vector<unsigned long long> h(ndbg);
     HIP_TRY(hipStreamSynchronize(stream));
