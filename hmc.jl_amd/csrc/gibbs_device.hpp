@@ -669,8 +669,8 @@ struct SweepShared {
     OutConst oc[2][64];
     // signal path with signals past the end date: the (scaled) emission values of the last `tail` steps, the
     // filtered probabilities at end_pos, and the current noise sample's last observation (by sample parity)
-    double ftail[SIG ? HMCG_MAXTAIL : 1][K];
-    double pf_rep[K];
+    double ftail[2][SIG ? HMCG_MAXTAIL : 1][K];      // by sweep parity: the outputs job of sweep s-1 runs beside the pdf phase of sweep s
+    double pf_rep[2][K];
     double y_last[2];
 };
 
@@ -1125,7 +1125,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     for (int j = tail - 1; j >= 0; --j) {
                         double g[K], nb[K];
 #pragma unroll
-                        for (int c = 0; c < K; ++c) g[c] = sh.ftail[j][c] * b[c];
+                        for (int c = 0; c < K; ++c) g[c] = sh.ftail[sw & 1][j][c] * b[c];
 #pragma unroll
                         for (int r = 0; r < K; ++r) {
                             double acc = 0.0;
@@ -1140,7 +1140,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     double tot = 0.0, mine = 0.0;
 #pragma unroll
                     for (int c = 0; c < K; ++c) {
-                        const double g = sh.pf_rep[c] * b[c];
+                        const double g = sh.pf_rep[sw & 1][c] * b[c];
                         tot += g;
                         mine = (c == si) ? g : mine;
                     }
@@ -1358,14 +1358,18 @@ void gibbs_sweeps_kernel(const KernelParams p)
             for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
                 __syncthreads();                                             // Ba
                 STAMP(0);
-                if (sweep > p.sweep_begin) job_outputs(sweep - 1);
-                STAMP(14);
                 if (wave == PREP_WAVE && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
                 STAMP(15);
                 job_uniform_trips(sweep);
                 STAMP(1);
                 __syncthreads();                                             // Bb
                 STAMP(2);
+                // the PREVIOUS sweep's per-draw outputs and forecasts (theta[par ^ 1] stays untouched until the next
+                // parameter phase), in the shadow of the primaries' pdf / product / scan phases (~5k cycles) -- not in the
+                // parameter phase, which the forecast job (2.3k cycles) would bound together with wave 0.  (Measured: in
+                // the shadow of the shorter backward pass instead, the helpers delayed barrier Be by ~0.9k cycles.)
+                if (sweep > p.sweep_begin) job_outputs(sweep - 1);
+                STAMP(14);
                 __syncthreads();                                             // Bc
                 __syncthreads();                                             // Bd
                 __syncthreads();                                             // Be
@@ -1612,7 +1616,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     const int j = t0 + l - (T - tail);
                     if (j >= 0 && j < tail) {
 #pragma unroll
-                        for (int s = 0; s < K; ++s) sh.ftail[j][s] = f[l][s];
+                        for (int s = 0; s < K; ++s) sh.ftail[par][j][s] = f[l][s];
                     }
                 }
             }
@@ -1754,7 +1758,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 for (int l = 0; l < L; ++l)
                     if (t0 + l == T - 1 - tail) {
 #pragma unroll
-                        for (int s = 0; s < K; ++s) sh.pf_rep[s] = pf[l][s];
+                        for (int s = 0; s < K; ++s) sh.pf_rep[par][s] = pf[l][s];
                     }
             }
         }
