@@ -1685,15 +1685,26 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int s = 0; s < K; ++s) av[s] = rho[s];
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // scalar: the loops over other waves branch, not select
+        // (the last wave runs NW-1 dependent vector-matrix products here and everyone waits for it at the next barrier:
+        //  the next wave total is fetched from LDS while the current product runs)
+        double Wn[KK];
+#pragma unroll
+        for (int i = 0; i < KK; ++i) Wn[i] = sh.wtot[0][i];
 #pragma unroll
         for (int ww = 0; ww < NW - 1; ++ww) {
             if (ww < wave_u) {
-                double nv[K];
+                double Wc[KK], nv[K];
+#pragma unroll
+                for (int i = 0; i < KK; ++i) Wc[i] = Wn[i];
+                if (ww + 1 < NW - 1) {
+#pragma unroll
+                    for (int i = 0; i < KK; ++i) Wn[i] = sh.wtot[ww + 1][i];
+                }
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    double acc = av[0] * sh.wtot[ww][s];
+                    double acc = av[0] * Wc[s];
 #pragma unroll
-                    for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
+                    for (int r = 1; r < K; ++r) acc = fma(av[r], Wc[r * K + s], acc);
                     nv[s] = acc;
                 }
 #pragma unroll
@@ -1715,6 +1726,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
             for (int s = 0; s < K; ++s) av[s] = nv[s];
         }
         // replay the normalised recursion over this thread's steps (:413-432)
+        // (carrying the UNNORMALISED vector and normalising each step off the chain was measured: +-0)
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             double nv[K], total = 0.0;
