@@ -644,8 +644,10 @@ struct SweepShared {
     static constexpr int NW = NT / 64;
     static constexpr int NCNT = K + K * K;
     static constexpr int NF = K * K + (SIG ? K : 0);     // count fields: C_ij, then (signal path) M_i = signal steps in state i
-    static constexpr int NPK = (NF + 1) / 2;
-    unsigned red_pk[NW][NPK];     // per-wave counts, two 16-bit fields per word (field e = i*K+j; K*K+i for M_i)
+    static constexpr int FW = (64 * L < 1024) ? 10 : 16;  // bits per wave-total field: a wave total is at most 64 L
+    static constexpr int FPK = 32 / FW;                  // fields per word: three 10-bit ones while L <= 15, else two
+    static constexpr int NPK = (NF + FPK - 1) / FPK;
+    unsigned red_pk[NW][NPK];     // per-wave counts, FPK fields per word (field e = i*K+j; K*K+i for M_i)
     double red_s1[SIG ? NW : 1][K];   // signal path: the same pivoted sums over the signal positions
     double red_s2[SIG ? NW : 1][K];
     int x_end;                    // X[T-1] of the chain state the statistics describe
@@ -1163,7 +1165,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     constexpr int NF = Sh::NF;
     constexpr int NWORD = (NF + FPW - 1) / FPW;
     constexpr int NPK = Sh::NPK;
-    static_assert(64 * L < 65536, "16-bit wave totals");
+    static_assert(64 * L < 65536, "wave totals fit their fields (10 bits while 64 L < 1024, else 16)");
     auto publish_stats = [&]() __attribute__((always_inline)) {
         // ---- transition counts C_ij: per-thread PB-bit fields -> 16-bit fields -> one DPP integer sum per word
         unsigned acc[NWORD];
@@ -1197,9 +1199,12 @@ void gibbs_sweeps_kernel(const KernelParams p)
         unsigned pk[NPK];
 #pragma unroll
         for (int d = 0; d < NPK; ++d) {
-            const int e0 = 2 * d, e1 = 2 * d + 1;
-            unsigned v = (acc[e0 / FPW] >> (PB * (e0 % FPW))) & ((1u << PB) - 1u);
-            if (e1 < NF) v |= ((acc[e1 / FPW] >> (PB * (e1 % FPW))) & ((1u << PB) - 1u)) << 16;
+            unsigned v = 0;
+#pragma unroll
+            for (int q = 0; q < Sh::FPK; ++q) {
+                const int e = Sh::FPK * d + q;
+                if (e < NF) v |= ((acc[e / FPW] >> (PB * (e % FPW))) & ((1u << PB) - 1u)) << (Sh::FW * q);
+            }
             pk[d] = wave_sum_u32_lane63(v);
         }
         // ---- pivoted sums by state: d1_i = sum (y - pivot_i), d2_i = sum (y - pivot_i)^2 over the observation
@@ -1403,7 +1408,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
             {
                 const int e = is_A ? role - K : 0;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) cT += (int)((sh.red_pk[ww][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                for (int ww = 0; ww < NW; ++ww) cT += (int)((sh.red_pk[ww][e / Sh::FPK] >> (Sh::FW * (e % Sh::FPK))) & ((1u << Sh::FW) - 1u));
                 cT = is_A ? cT : 0;
             }
             // N_i = sum_j C_ij + [X[T-1] == i]: quad sums of the A lanes, handed to the sig2 lanes as scalars
@@ -1442,7 +1447,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                         {
                             const int e = KK + role;
 #pragma unroll
-                            for (int ww = 0; ww < NW; ++ww) Mi += (int)((sh.red_pk[ww][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                            for (int ww = 0; ww < NW; ++ww) Mi += (int)((sh.red_pk[ww][e / Sh::FPK] >> (Sh::FW * (e % Sh::FPK))) & ((1u << Sh::FW) - 1u));
                         }
                         const int Ni = c - Mi;
                         double g1 = 0.0, g2 = 0.0;
@@ -1883,25 +1888,28 @@ void gibbs_sweeps_kernel(const KernelParams p)
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
             uint32_t m = 0;
+            // the draw under the uniform 1/K law (a failed guard, :476-480) does not depend on the successor state: once per step
+            int idx_uni = 0;
+            {
+                double ucum = 0.0;
+#pragma unroll
+                for (int r = 0; r < K - 1; ++r) { ucum += 1.0 / K; idx_uni += (ucum <= ux[l]) ? 1 : 0; }
+            }
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 // p[r] = Pf[t+1,r,s] is proportional to pif[t,r] * A[r,s]; its sum over r equals the
                 // unsorted pif[t+1,s], which drives the eps() guard (:472, quirk 7).  A failed guard
                 // (common for states far from y[t+1]) selects the uniform 1/K law (:476-480).
                 const double guard = (l + 1 < L) ? pf[(l + 1 < L) ? l + 1 : l][s] : pfn_last[s];
-                const bool gok = guard > EPS64;
-                double tot = 0.0, ucum = 0.0;
+                double tot = 0.0;
                 int idx = 0;
                 double cum[K];
 #pragma unroll
                 for (int r = 0; r < K; ++r) { tot = fma(pf[l][r], A[r][s], tot); cum[r] = tot; }
-                const double thr = gok ? ux[l] * tot : ux[l];
+                const double thr = ux[l] * tot;
 #pragma unroll
-                for (int r = 0; r < K - 1; ++r) {
-                    ucum += 1.0 / K;
-                    const double c = gok ? cum[r] : ucum;
-                    idx += (c <= thr) ? 1 : 0;
-                }
+                for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
+                idx = (guard > EPS64) ? idx : idx_uni;          // one integer select instead of selecting every threshold
                 m |= (uint32_t)idx << (8 * s);
             }
             if constexpr (K < 4) m |= BMAP_IDENTITY & (0xFFFFFFFFu << (8 * K));       // unused bytes: identity
@@ -1941,7 +1949,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
         x_end = xlast;
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
-            if (t0 + l < T) { sin = bmap_apply(gmap[l], sin); x[l] = sin; }
+            sin = bmap_apply(gmap[l], sin);      // (slots at or beyond T carry the identity: what lands in x[] there is never read)
+            x[l] = sin;
         }
         // pivots for the next sweep's one-pass statistics: this sweep's state means (X labels are unsorted)
 #pragma unroll
