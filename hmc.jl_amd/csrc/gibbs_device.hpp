@@ -1659,7 +1659,9 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 for (int i = 0; i < KK; ++i) Q[i] = N[i];
             }
         }
-        rescale_pow2<KK>(Q);
+        // (every step was scaled so that its largest pdf lies in [0.5, 1): up to four steps per thread and two scan levels
+        //  -- sixteen factors -- stay far inside the fp64 range without help; longer chunks are brought back here)
+        if constexpr (L > 4 || SMOOTH) rescale_pow2<KK>(Q);
         double Qloc[SMOOTH ? KK : 1];                // this thread's own product, for the backward (suffix) scan
         if constexpr (SMOOTH) {
 #pragma unroll
