@@ -777,6 +777,13 @@ void gibbs_sweeps_kernel(const KernelParams p)
 
     for (int i = tid; i < EXPTAB_N; i += NT + 64 * NH) sh.exptab[i] = exp2((double)i * (1.0 / EXPTAB_N));   // correctly rounded enough (OCML exp2, < 1 ulp)
     // ---- load the window's observations (once per launch) ----
+    // Steps at or beyond T ("padded": t0 + l >= T) carry the pseudo-state XPAD.  For K <= 3 that is the out-of-range value K,
+    // which no `x == i` test matches and which the backward pass keeps in place by itself (the maps beyond T-1 are the
+    // constant map to K): the statistics then need no `t < T` predicates -- eight lane masks that used to live in SGPRs
+    // across the sweep loop and came back through v_readlane.  (K = 4 fills the byte-map selector range, so it keeps 0
+    // and the predicates.)
+    constexpr int XPAD = K < 4 ? K : 0;
+    constexpr bool PADMARK = K < 4;
     double y[L];
     int x[L];
     bool bad = false;
@@ -785,7 +792,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         const bool v = (t0 + l) < T;
         y[l] = v ? p.Y[(size_t)w * p.ldY + t0 + l] : 0.0;
         bad |= v && !isfinite(y[l]);
-        x[l] = 0;
+        x[l] = XPAD;
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
         if (tid == 0) atomicOr(&p.status[w], HMCG_ST_NONFINITE);
@@ -893,7 +900,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                     const double d = fabs(y[l] - mu0[k]);
                     if (d < bd) { bd = d; best = k; }
                 }
-                x[l] = (t0 + l < T) ? best : 0;
+                x[l] = (t0 + l < T) ? best : XPAD;
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) pivot[k] = mu0[k];
@@ -904,7 +911,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     // first state of the next thread's chunk (X at t0+L), and X[T-1]
     int xnext = 0;
     if (!helper) sh.xfirst[tid] = x[0];
-    if (tid == 0) sh.xfirst[NT] = 0;
+    if (tid == 0) sh.xfirst[NT] = XPAD;
     if (tid == owner) {
 #pragma unroll
         for (int l = 0; l < L; ++l) if (l == l_last) sh.x_end = x[l];
@@ -1165,6 +1172,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     constexpr int NF = Sh::NF;
     constexpr int NWORD = (NF + FPW - 1) / FPW;
     constexpr int NPK = Sh::NPK;
+    constexpr bool PADCNT = PADMARK && !SIG && NWORD == 1 && NF < FPW;    // counts without `t + 1 < T` predicates
     static_assert(64 * L < 65536, "wave totals fit their fields (10 bits while 64 L < 1024, else 16)");
     auto publish_stats = [&]() __attribute__((always_inline)) {
         // ---- transition counts C_ij: per-thread PB-bit fields -> 16-bit fields -> one DPP integer sum per word
@@ -1174,9 +1182,13 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int xn = (l + 1 < L) ? x[(l + 1 < L) ? l + 1 : l] : xnext;
-            const int code = x[l] * K + xn;
+            const int code = PADCNT ? x[l] + K * xn : x[l] * K + xn;
             const bool pv = (t0 + l + 1) < T;
-            if constexpr (NWORD == 1) {
+            if constexpr (PADCNT) {
+                // field j*K+i for the pair i -> j: a pair whose successor is padded (xn = K; a padded step is never
+                // followed by a real one) has code >= K*K, and all of those land in the spare field K*K
+                acc[0] += 1u << (PB * min(code, KK));
+            } else if constexpr (NWORD == 1) {
                 acc[0] += pv ? (1u << (PB * code)) : 0u;
             } else {
 #pragma unroll
@@ -1224,7 +1236,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
             const double dl = y[l] - pvt;
             const int t = t0 + l;
             const bool issig = SIG && t >= sb && t < se;
-            const int xs = (t < T && !issig) ? x[l] : -1;
+            const int xs = PADMARK ? (issig ? -1 : x[l]) : ((t < T && !issig) ? x[l] : -1);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const double dm = (xs == i) ? dl : 0.0;
@@ -1406,7 +1418,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
             // transition count C_e of this lane's A role (e = role - K), summed over the waves' packed words
             int cT = 0;
             {
-                const int e = is_A ? role - K : 0;
+                const int e = is_A ? (PADCNT ? qj * K + qi : role - K) : 0;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) cT += (int)((sh.red_pk[ww][e / Sh::FPK] >> (Sh::FW * (e % Sh::FPK))) & ((1u << Sh::FW) - 1u));
                 cT = is_A ? cT : 0;
@@ -1915,7 +1927,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 m |= (uint32_t)idx << (8 * s);
             }
             if constexpr (K < 4) m |= BMAP_IDENTITY & (0xFFFFFFFFu << (8 * K));       // unused bytes: identity
-            m = (t == T - 1) ? bmap_const(xlast) : (t > T - 1 ? BMAP_IDENTITY : m);
+            m = (t == T - 1) ? bmap_const(xlast) : (t > T - 1 ? (PADMARK ? bmap_const(XPAD) : BMAP_IDENTITY) : m);
             gmap[l] = m;
             G = bmap_compose(m, G);      // G = g_{t0+l} o (g_{t0+l+1} o ...)
         }
@@ -1946,12 +1958,12 @@ void gibbs_sweeps_kernel(const KernelParams p)
         for (int ww = NW - 1; ww >= 1; --ww) if (ww > wave_u) Rw = bmap_compose(sh.wmap[ww], Rw);
         const uint32_t Hx = (uint32_t)dpp_i32<DPP_WAVE_SHL1, 0xF>((int)BMAP_IDENTITY, (int)Hm);   // lane 63: identity
         const uint32_t Sfx = bmap_compose(Hx, Rw);     // everything after this thread's chunk
-        int sin = bmap_apply(Sfx, 0);                  // constant map below T-1: evaluate anywhere
+        int sin = bmap_apply(Sfx, XPAD);               // constant map below T-1; the identity (-> XPAD) for the last thread
         xnext = sin;
         x_end = xlast;
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
-            sin = bmap_apply(gmap[l], sin);      // (slots at or beyond T carry the identity: what lands in x[] there is never read)
+            sin = bmap_apply(gmap[l], sin);      // (slots at or beyond T: XPAD when PADMARK, else a value that is never read)
             x[l] = sin;
         }
         // pivots for the next sweep's one-pass statistics: this sweep's state means (X labels are unsorted)
