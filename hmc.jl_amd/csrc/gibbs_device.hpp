@@ -375,6 +375,32 @@ __device__ __forceinline__ unsigned wave_sum_u32_lane63(unsigned v)
     return v;
 }
 
+// the same for N words at once: the N independent chains are interleaved in one block, so a word's next level is
+// N - 1 instructions behind its previous one and the DPP read-after-write wait (two states) needs no s_nop from N = 3 on
+#define HMCG_DPP_ADD3(CTRL) \
+    "v_add_u32_dpp %0, %0, %0 " CTRL "\n\tv_add_u32_dpp %1, %1, %1 " CTRL "\n\tv_add_u32_dpp %2, %2, %2 " CTRL "\n\t"
+#define HMCG_DPP_ADD2(CTRL) "v_add_u32_dpp %0, %0, %0 " CTRL "\n\tv_add_u32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+template <int N>
+__device__ __forceinline__ void wave_sum_words_lane63(unsigned (&v)[N])
+{
+    if constexpr (N == 3) {
+        asm volatile("s_nop 1\n\t" HMCG_DPP_ADD3("row_shr:1 row_mask:0xf bank_mask:0xf") HMCG_DPP_ADD3("row_shr:2 row_mask:0xf bank_mask:0xf")
+                         HMCG_DPP_ADD3("row_shr:4 row_mask:0xf bank_mask:0xf") HMCG_DPP_ADD3("row_shr:8 row_mask:0xf bank_mask:0xf")
+                             HMCG_DPP_ADD3("row_bcast:15 row_mask:0xa bank_mask:0xf") HMCG_DPP_ADD3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    } else if constexpr (N == 2) {
+        asm volatile("s_nop 1\n\t" HMCG_DPP_ADD2("row_shr:1 row_mask:0xf bank_mask:0xf") HMCG_DPP_ADD2("row_shr:2 row_mask:0xf bank_mask:0xf")
+                         HMCG_DPP_ADD2("row_shr:4 row_mask:0xf bank_mask:0xf") HMCG_DPP_ADD2("row_shr:8 row_mask:0xf bank_mask:0xf")
+                             HMCG_DPP_ADD2("row_bcast:15 row_mask:0xa bank_mask:0xf") HMCG_DPP_ADD2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     : "+v"(v[0]), "+v"(v[1]));
+    } else {
+#pragma unroll
+        for (int d = 0; d < N; ++d) v[d] = wave_sum_u32_lane63(v[d]);
+    }
+}
+#undef HMCG_DPP_ADD3
+#undef HMCG_DPP_ADD2
+
 __device__ __forceinline__ double wave_min(double v)
 {
 #pragma unroll
@@ -1217,8 +1243,9 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 const int e = Sh::FPK * d + q;
                 if (e < NF) v |= ((acc[e / FPW] >> (PB * (e % FPW))) & ((1u << PB) - 1u)) << (Sh::FW * q);
             }
-            pk[d] = wave_sum_u32_lane63(v);
+            pk[d] = v;
         }
+        wave_sum_words_lane63<NPK>(pk);
         // ---- pivoted sums by state: d1_i = sum (y - pivot_i), d2_i = sum (y - pivot_i)^2 over the observation
         // positions (and, on the signal path, the same two sums over the signal positions)
         double d1[K], d2[K], s1[SIG ? K : 1], s2[SIG ? K : 1];
