@@ -392,12 +392,18 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         }
     };
 
+#ifdef HMCG_STAMPS
+    unsigned long long stamp_acc[HMCG_NSTAMP];
+    for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
         rng.sweep = (uint32_t)sweep;
         const int par = sweep & 1;
         ThetaBufBig<K>& th = sh.th[par];
         const bool last_sweep = sweep + 1 == p.sweep_end;
         __syncthreads();                                                     // Ba
+        STAMP(0);
         if (wave == 0) {
             // ---- parameter draws; roles [0,K) sig2/mu, [K, K+K^2) A entries; ceil(NG/64) passes ----
             const RngBuf<K>& rb = sh.rb[par];
@@ -497,7 +503,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             const int per = (nblk + NSH - 1) / NSH;
             job_uniforms(sweep, shadow_wave * per, min((shadow_wave + 1) * per, nblk));
         }
+        STAMP(1);
         __syncthreads();                                                     // Bb
+        STAMP(2);
         // ---- forward filter: local product of this thread's L matrices A diag(f_t) ----
         double Q[KK];
 #pragma unroll
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             for (int i = 0; i < KK; ++i) Qloc[i] = Q[i];
         }
         (void)Qloc;
+        STAMP(4);
         scan_level_rowwise<K, DPP_ROW_SHR1, 0xF>(Q, N);
         scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(N, Q);
         rescale_pow2<KK>(Q);
@@ -571,7 +580,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
             for (int i = 0; i < KK; ++i) sh.wtot[wave][i] = Q[i];
         }
+        STAMP(5);
         __syncthreads();                                                     // Bc
+        STAMP(6);
         // prefix vector rho' * (earlier waves) * (exclusive lane prefix)
         double av[K];
 #pragma unroll
@@ -750,7 +761,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
         }
         if (tid == NT - 1) maps[cap - 1] = map_identity<K>();
+        STAMP(7);
         __syncthreads();                                                     // Bd
+        STAMP(8);
         // X[T-1] ~ Categorical(sorted pif[T-1,:]) (:464), redundantly in every thread
         int xlast = 0;
         {
@@ -776,6 +789,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             maps[t] = m;
             G = map_compose<K>(m, G);
         }
+        STAMP(9);
         uint32_t Hm = G;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -784,7 +798,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             Hm = (lane + d < 64) ? C : Hm;
         }
         if (lane == 0) sh.wmap[wave] = Hm;
+        STAMP(10);
         __syncthreads();                                                     // Be
+        STAMP(11);
         uint32_t Rw = map_identity<K>();
 #pragma unroll
         for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? map_compose<K>(sh.wmap[ww], Rw) : Rw;
@@ -797,9 +813,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         }
         x_end = xlast;
         if (tid < K) sh.pivot[tid] = th.mu[tid];                             // pivots of the next one-pass statistics
+        STAMP(12);
         __syncthreads();                                                     // Bf: xs, pivot complete
         publish_stats();
+        STAMP(13);
     }
+#ifdef HMCG_STAMPS
+    if (lane == 0 && p.dbg)
+        for (int i = 0; i < HMCG_NSTAMP; ++i) p.dbg[((size_t)w * NW + wave) * HMCG_NSTAMP + i] = stamp_acc[i];
+#endif
 
     // ---- epilogue ----
     __syncthreads();
