@@ -424,7 +424,8 @@ __device__ __forceinline__ void rescale_pow2(double (&q)[N])
 #pragma unroll
     for (int i = 1; i < N; ++i) m = max(m, (unsigned)__double2hiint(q[i]));
     const int be = (int)(m >> 20);                       // biased exponent of the largest entry
-    const int e = (be > 0 && be < 2040) ? 1022 - be : 0;
+    int e = (be > 0 && be < 2040) ? 1022 - be : 0;
+    asm volatile("" : "+v"(e));                          // one select on the exponent -- not one per entry on ldexp's results
 #pragma unroll
     for (int i = 0; i < N; ++i) q[i] = ldexp(q[i], e);
 }
