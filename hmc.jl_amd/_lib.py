@@ -46,7 +46,8 @@ class Extras(C.Structure):
                 ("x_final", C.c_void_p), ("pif_final", C.c_void_p), ("xstate", C.c_void_p), ("sumacc", C.c_void_p), ("window_ids", C.c_void_p),
                 ("sig_range", C.c_void_p), ("save_range", C.c_void_p), ("sigma_signal", C.c_void_p),
                 ("sigvals", C.c_void_p), ("nsave_ld", C.c_int32), ("reserved2", C.c_int32),
-                ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p), ("pi_filter_mean", C.c_void_p)]
+                ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p), ("pi_filter_mean", C.c_void_p),
+                ("corr", C.c_void_p)]
 
 
 class Timing(C.Structure):
@@ -153,13 +154,16 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
-                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None):
+                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None, want_corr=False):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,).
     devices: a list of HIP ordinals -> hmcg_estimate_batch_multi (windows partitioned over those GPUs).
     out: a dict returned by an earlier call of the same shape -- its arrays are reused (a caller that owns its
-    buffers, as a Julia or C caller does, pays no allocation or first-touch page faults per call)."""
+    buffers, as a Julia or C caller does, pays no allocation or first-touch page faults per call).
+    want_corr: out["corr"] (W, NC, NC), NC = 3K + K^2 + 1 -- the correlation matrix calccorr (src/Hmc.jl:1094-1163) builds
+    per end date from the per-draw CSV files, accumulated on the device from the rounded draws (extras.corr); works with
+    want_draws=False (the draws then never leave the device)."""
     L = load()
     Y = np.ascontiguousarray(Y, dtype=np.float64)
     W, ldY = Y.shape
@@ -213,6 +217,10 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     if want_filter_mean:
         out["pi_filter_mean"] = np.zeros((W, ldY, K))
         ex.pi_filter_mean = out["pi_filter_mean"].ctypes.data
+    if want_corr:
+        NC = 3 * K + K * K + 1
+        out["corr"] = np.zeros((W, NC, NC))
+        ex.corr = out["corr"].ctypes.data
     if want_state:
         out["x_final"] = np.zeros((W, ldY), dtype=np.int32)
         out["pif_final"] = np.zeros((W, ldY, K))
@@ -251,7 +259,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     # plausible-looking zero (the reference would have thrown, src/Hmc.jl:435)
     skipped = (out["status"] & ST_SKIPPED) != 0
     if skipped.any():
-        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final"):
+        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final", "corr"):
             if name in out:
                 out[name][skipped] = np.nan
     out["kernel_ms"] = tm.kernel_ms

@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "../../include/hmcg.h"
+#include "round5.hpp"
 
 namespace hmcg {
 
@@ -581,19 +582,6 @@ __device__ __forceinline__ uint32_t bmap_const(int v) { return (uint32_t)v * 0x0
 __device__ __forceinline__ uint32_t bmap_compose(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(a, a, b); }
 __device__ __forceinline__ int bmap_apply(uint32_t m, int s) { return (int)((m >> (8 * s)) & 0xFFu); }
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_WAVE_SHL1 = 0x130;
-
-// Julia round(x; digits=5) (basicsave, src/Hmc.jl:719) = rint(x * 1e5) / 1e5 with a CORRECTLY ROUNDED quotient, as the
-// oracle and a host-side mean of the per-draw CSV cells compute it: reciprocal estimate q0 = fl(n * 1e-5), exact fp64
-// residual r = n - q0 * 1e5 (one FMA), correction q0 + r * 1e-5.  For |n| < 2^53 the corrected value is the correctly
-// rounded n / 1e5 (Markstein's division sequence with an exact residual; 1e-5 is 1/1e5 to half an ulp).
-__device__ __forceinline__ double round5(double x)
-{
-    const double n = rint(x * 1e5);
-    const double q0 = n * 1e-5;
-    const double r = fma(-q0, 1e5, n);
-    const double q = fma(r, 1e-5, q0);
-    return isfinite(q) ? q : x;
-}
 
 // forecast (src/Hmc.jl:658-667): (pi' A^h) . mu, A^h on Julia's power_by_squaring schedule.
 template <int K>

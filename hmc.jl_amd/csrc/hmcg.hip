@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 
+#include "moments.hpp"
 #include "variants.hpp"
 
 namespace {
@@ -95,6 +96,7 @@ struct DeviceCtx {
     hipEvent_t evk[RING] = {}, evc[RING] = {};        // chunk pipeline: kernel done / copy done
     int cu_count = 0;
     Arena dev, pin;
+    Arena mom;                     // device entry: the draw-moment tables behind extras.corr
 };
 DeviceCtx g_ctx[HMCG_MAXDEV];
 std::mutex g_init_mu;
@@ -145,6 +147,7 @@ void destroy_context(DeviceCtx& c)
     for (int i = 0; i < RING; ++i) { (void)hipEventDestroy(c.evk[i]); (void)hipEventDestroy(c.evc[i]); }
     c.dev.release();
     c.pin.release();
+    c.mom.release();
     c.stream = c.copy = nullptr;
     c.ready = false;
     c.device = -1;
@@ -230,6 +233,16 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     }
     if (cfg->blend_mask < 0 || (cfg->H < 31 && (cfg->blend_mask >> cfg->H) != 0)) { set_err("blend_mask has bits beyond H"); return HMCG_E_BADARG; }
     if (ex && ex->sigvals && ex->nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
+    if (ex && ex->corr) {
+        if (use_sig || n_samples > 1 || cfg->H < 1 || cfg->nrun < 2) {
+            set_err("extras.corr: base runs only (no signal path), H >= 1 (the forecast column) and nrun >= 2");
+            return HMCG_E_BADARG;
+        }
+        if (resume || cfg->sweep_base != 0 || (cfg->sweep_count > 0 && cfg->sweep_count < cfg->burnin + cfg->nrun)) {
+            set_err("extras.corr needs the whole run in one call (no RESUME / sweep_base / sweep_count)");
+            return HMCG_E_BADARG;
+        }
+    }
     const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
     if (use_sig && cfg->K >= 5) { set_err("signal path: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     if (cfg->sweep_base > n_samples * (cfg->burnin + cfg->nrun)) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
@@ -361,6 +374,10 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
                 "([W][ldY][K]: the running sweep's filtered probabilities pass through it)");
         return HMCG_E_BADARG;
     }
+    if (ex && ex->corr && (!dmu || !dsig2 || !dA || !dpi_end || !dfcast)) {
+        set_err("extras.corr on the device entry needs all five per-draw outputs");
+        return HMCG_E_BADARG;
+    }
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
     hmcg::KernelParams p = base_params(cfg, cfg->W, dY, dT, dyreal, dstatus, ex, pl.use_sig);
     const int total_sweeps = p.n_samples * (cfg->burnin + cfg->nrun);
@@ -384,6 +401,15 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
 #endif
     launch_kernel(pl, p, stream);
     HIP_TRY(hipGetLastError());
+    if (ex && ex->corr) {
+        // correlations of the rounded draws (calccorr): one pass over the draw arrays while they are in HBM
+        const size_t mbytes = sizeof(double) * (size_t)cfg->W * hmcg_host::moments_stride(cfg->K);
+        if (c.mom.cap < mbytes) HIP_TRY(hipStreamSynchronize(stream));        // growing the table frees the old one
+        if (c.mom.ensure(mbytes)) { set_err("workspace allocation failed (%zu B device)", mbytes); return HMCG_E_NOMEM; }
+        hmcg_host::MomentsArgs ma{dmu, dsig2, dpi_end, dA, dfcast, reinterpret_cast<double*>(c.mom.base), cfg->nrun, cfg->nrun, cfg->W, cfg->K, cfg->H, true};
+        HIP_TRY(hmcg_host::launch_moments(ma, stream));
+        HIP_TRY(hmcg_host::launch_corr_finalize(reinterpret_cast<double*>(c.mom.base), ex->corr, cfg->W, cfg->K, stream));
+    }
 #ifdef HMCG_STAMPS
     rc = print_stamps(p, pl, ddbg, ndbg, stream);
     (void)hipFree(ddbg);
@@ -468,8 +494,15 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     struct Col { double* host; size_t ncol; size_t off; };
     Col cols[5] = { {h.mu, K, 0}, {h.sig2, K, 0}, {h.A, K * K, 0}, {h.pi_end, K, 0}, {h.fcast, 2 * H, 0} };
     size_t ncols = 0;
-    for (Col& cc : cols) { if (!cc.host || nd_total == 0) cc.ncol = 0; cc.off = ncols; ncols += cc.ncol; }
+    const bool want_corr = ex && ex->corr;          // needs every draw column on the device, wanted by the caller or not
+    bool copy_out = false;
+    for (Col& cc : cols) {
+        if (!(cc.host || want_corr) || nd_total == 0) cc.ncol = 0;
+        if (cc.host && cc.ncol) copy_out = true;
+        cc.off = ncols; ncols += cc.ncol;
+    }
     const bool stream_draws = ncols > 0;
+    const size_t NCC = (size_t)hmcg_host::corr_columns(cfg->K), mom_stride = hmcg_host::moments_stride(cfg->K);
 
     const int total_sweeps = n_samples * (cfg->burnin + cfg->nrun);
     int sb = cfg->sweep_base, se = total_sweeps;
@@ -510,6 +543,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const size_t o_dsr = (ex && ex->sig_range) ? LD.add(8 * N) : 0, o_dsvr = (ex && ex->save_range) ? LD.add(8 * N) : 0;
     const size_t o_dep = (ex && ex->end_pos) ? LD.add(4 * N) : 0, o_dss = (ex && ex->sigma_signal) ? LD.add(8 * N) : 0;
     const size_t o_dsv = want_sv ? LD.add(8 * N * nsv) : 0;
+    const size_t o_dmom = want_corr ? LD.add(8 * N * mom_stride) : 0, o_dcorr = want_corr ? LD.add(8 * N * NCC * NCC) : 0;
     // pinned staging: inputs, small outputs, chunk ring, one-off big extras
     const size_t o_pY = LP.add(8 * N * ld), o_pT = LP.add(4 * N), o_pst = LP.add(4 * N), o_pwid = LP.add(4 * N);
     const size_t o_pyr = (h.yreal && H) ? LP.add(8 * N * H) : 0;
@@ -522,6 +556,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const size_t o_psr = (ex && ex->sig_range) ? LP.add(8 * N) : 0, o_psvr = (ex && ex->save_range) ? LP.add(8 * N) : 0;
     const size_t o_pep = (ex && ex->end_pos) ? LP.add(4 * N) : 0, o_pss = (ex && ex->sigma_signal) ? LP.add(8 * N) : 0;
     const size_t o_psv = want_sv ? LP.add(8 * N * nsv) : 0;
+    const size_t o_pcorr = want_corr ? LP.add(8 * N * NCC * NCC) : 0;
     if (c.dev.ensure(LD.total) || c.pin.ensure(LP.total)) {
         set_err("workspace allocation failed (%zu B device, %zu B pinned)", LD.total, LP.total);
         return HMCG_E_NOMEM;
@@ -621,6 +656,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         for (int i = 0; i < n; ++i) {
             const size_t g = row(i);
             for (const Col& cc : cols) {
+                if (!cc.host) continue;
                 for (size_t q = 0; q < cc.ncol; ++q)
                     memcpy(cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0,
                            src + ndc * (cc.off * N + q + cc.ncol * (size_t)i), 8 * ndc);
@@ -661,12 +697,19 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (stream_draws) {
             HIP_TRY(hipEventRecord(c.evk[slot], s));
             HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
-            if (ndc > 0)
+            if (ndc > 0 && copy_out)
                 HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, c.copy));
             HIP_TRY(hipEventRecord(c.evc[slot], c.copy));
+            if (want_corr && ndc > 0) {
+                // second moments of the chunk's rounded draws, in HBM, beside the chunk's copy-out (calccorr)
+                hmcg_host::MomentsArgs ma{p.mu, p.sig2, p.pi_end, p.A, p.fcast, DP(double, o_dmom), (long long)ndc, (long long)ndc,
+                                          n, cfg->K, cfg->H, ch.d0 == 0};
+                HIP_TRY(hmcg_host::launch_moments(ma, s));
+            }
         }
     }
     if (timing) HIP_TRY(hipEventRecord(tev[(size_t)nch], s));
+    if (want_corr) HIP_TRY(hmcg_host::launch_corr_finalize(DP(double, o_dmom), DP(double, o_dcorr), n, cfg->K, s));
 
     // ---- small outputs and one-off extras: D2H on the compute stream (after the last kernel) ----
 #define D2H(poff, doff, bytes) HIP_TRY(hipMemcpyAsync(P + (poff), D + (doff), (bytes), hipMemcpyDeviceToHost, s))
@@ -677,6 +720,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
     if (want_fm) D2H(o_pfm, o_dfm, 8 * N * ld * K);
     if (want_sv) D2H(o_psv, o_dsv, 8 * N * nsv);
+    if (want_corr) D2H(o_pcorr, o_dcorr, 8 * N * NCC * NCC);
     if (ex && ex->xstate) D2H(o_pxs, o_dxs, N * ld);
     if (ex && ex->sumacc) D2H(o_pacc, o_dacc, 8 * N * (NS + K));
 #undef D2H
@@ -697,6 +741,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (want_sm) memcpy(ex->pi_smooth_mean + g * ld * K, PP(double, o_psm) + (size_t)i * ld * K, 8 * ld * K);
         if (want_fm) memcpy(ex->pi_filter_mean + g * ld * K, PP(double, o_pfm) + (size_t)i * ld * K, 8 * ld * K);
         if (want_sv) memcpy(ex->sigvals + g * nsv, PP(double, o_psv) + (size_t)i * nsv, 8 * nsv);
+        if (want_corr) memcpy(ex->corr + g * NCC * NCC, PP(double, o_pcorr) + (size_t)i * NCC * NCC, 8 * NCC * NCC);
         if (ex && ex->xstate) memcpy(ex->xstate + g * ld, PP(uint8_t, o_pxs) + (size_t)i * ld, ld);
         if (ex && ex->sumacc) memcpy(ex->sumacc + g * (NS + K), PP(double, o_pacc) + (size_t)i * (NS + K), 8 * (NS + K));
     }

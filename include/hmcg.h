@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 103
+#define HMCG_VERSION 104
 #define HMCG_MAXH 8
 #define HMCG_MAXTAIL 32         /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
@@ -145,7 +145,17 @@ typedef struct hmcg_extras {
                                    sorted labels (what the reference's older API returned as "pib" and averaged per date in
                                    data/output/official_insample/forecats_insample.csv, columns s1..s3).  Runs on the same
                                    kernel variants as pi_smooth_mean */
+    double* corr;               /* [W][NC][NC] optional, NC = HMCG_CORR_COLUMNS(K): Pearson correlations between the per-draw
+                                   outputs of each window over its kept draws, columns mu_1..K | sigma_1..K | pi_1..K |
+                                   vec(A) column-major | forecast of horizons[0] -- the matrix calccorr (src/Hmc.jl:1094-1163)
+                                   computes per end date from the 5-digit-rounded per-draw CSV files, here taken from the
+                                   rounded draws while they are in HBM (second moments about the first draw, accumulated in
+                                   draw order, chunk by chunk).  Needs all five per-draw outputs (mu, sig2, A, pi_end, fcast
+                                   with H >= 1; the host entries accept NULL for them and then keep the draws on the device),
+                                   n_samples <= 1 and the whole run in one call (no sweep_base / sweep_count / RESUME).  A
+                                   constant column gives NaN, as Statistics.cor does */
 } hmcg_extras;
+#define HMCG_CORR_COLUMNS(K) (3 * (K) + (K) * (K) + 1)
 
 typedef struct hmcg_timing {
     double kernel_ms;        /* HIP-event time of the sweep kernel(s) on the launch stream (summed over the chunks of a call) */
