@@ -12,6 +12,7 @@ ABI.  Names, argument meaning and result layout follow the reference:
     forecast            src/Hmc.jl:658-667
     saveresults/basicsave   src/Hmc.jl:707-748   (five per-window CSVs)
     runaggregate layout src/Hmc.jl:1025-1078 (`*_summary.csv`)
+    calccorr            src/Hmc.jl:1094-1163 (correlations.xlsx; matrices from the files or from the device)
 
 New (the reference batches by launching one SLURM task per window,
 slurmscripts/base_estimation.sh:5): `estimatewindows`, one call for many windows.
@@ -325,6 +326,7 @@ class BatchResult:
         self.summary = res["summary"]          # (W, 3K+K^2+2H)
         self.status = res["status"]
         self.kernel_ms = res.get("kernel_ms")
+        self.corr = res.get("corr")            # (W, NC, NC) with corr=True: calccorr's matrix per window (corrnames)
         self._res = res if keep_draws else None
 
     def samples(self, w):
@@ -334,12 +336,13 @@ class BatchResult:
         return _unpack(self._res, w, o.Nrun, o.D, len(o.horizons), enddate(o))
 
 
-def estimatewindows(rawdata, dates, endIndices, startIndex=1, keep_draws=False, device=0, window_ids=None, **kwargs):
+def estimatewindows(rawdata, dates, endIndices, startIndex=1, keep_draws=False, device=0, window_ids=None, corr=False, **kwargs):
     """Batched estimatemodel over many expanding windows (one GPU call).
 
     Window w uses sampleRange = startIndex:endIndices[w], endIndex = endIndices[w]; the
     remaining keyword arguments are estopt's.  RNG stream ids default to the position
-    in `endIndices`; pass window_ids to pin them (sharded runs)."""
+    in `endIndices`; pass window_ids to pin them (sharded runs).  corr=True also accumulates, on the device, the
+    correlation matrix between each window's per-draw outputs (calccorr, src/Hmc.jl:1094-1163) -> BatchResult.corr."""
     if startIndex != 1:
         raise ValueError("windows must start at index 1 (see estopt)")
     rawdata = np.asarray(rawdata, dtype=np.float64)
@@ -358,7 +361,7 @@ def estimatewindows(rawdata, dates, endIndices, startIndex=1, keep_draws=False, 
         Y[w, :Tw[w]] = makey(o)
         yreal[w] = _yreal_row(rawdata, o.endIndex, o.horizons)
     res = _lib.estimate_batch_host(Y, Tw, o0.D, o0.burnin, o0.Nrun, tuple(o0.horizons), yreal, seed=o0.seed,
-                                   device=device, want_draws=keep_draws, window_ids=window_ids)
+                                   device=device, want_draws=keep_draws, window_ids=window_ids, want_corr=corr)
     return BatchResult(opts, res, keep_draws)
 
 
@@ -595,3 +598,145 @@ def calcdispersion(datadir):
         _write_csv(path, h, r)
         written.append(path)
     return written
+
+
+# ------------------------------------------------------------ correlation workbook --
+# calccorr (src/Hmc.jl:1094-1163): per end date, the correlation matrix between the per-draw columns
+# mu_1..K | sigma_1..K | pi_1..K | trans_* (file order) | forecast_<first horizon>, one workbook sheet per date plus, on
+# the first sheet, the forecast's row of every date.  The matrices come either from the per-draw CSV files (as upstream:
+# file in, file out, no GPU) or straight from the device (estimatewindows(..., corr=True): extras.corr, no per-draw file).
+
+def corrnames(K, horizons):
+    """Labels of a correlation matrix: what calccorr derives from the CSV headers (:1104,1109,1114,1122)."""
+    return (["μ%d" % i for i in range(1, K + 1)] + ["σ%d" % i for i in range(1, K + 1)] + ["π%d" % i for i in range(1, K + 1)]
+            + ["trans_%d_%d" % (i, j) for j in range(1, K + 1) for i in range(1, K + 1)] + ["forecast_%d" % horizons[0]])
+
+
+def _xlsx_col(c):
+    s = ""
+    c += 1
+    while c:
+        c, r = divmod(c - 1, 26)
+        s = chr(65 + r) + s
+    return s
+
+
+def _xlsx_sheet(cells):
+    """cells: {(row, col): value} (0-based) -> worksheet XML; numbers as numeric cells, NaN / text as inline strings."""
+    from xml.sax.saxutils import escape
+    rows = {}
+    for (r, c), v in cells.items():
+        rows.setdefault(r, []).append((c, v))
+    out = ['<?xml version="1.0" encoding="UTF-8" standalone="yes"?>\n'
+           '<worksheet xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main"><sheetData>']
+    for r in sorted(rows):
+        out.append('<row r="%d">' % (r + 1))
+        for c, v in sorted(rows[r]):
+            ref = "%s%d" % (_xlsx_col(c), r + 1)
+            if isinstance(v, (int, float, np.floating)) and np.isfinite(v):
+                out.append('<c r="%s"><v>%s</v></c>' % (ref, repr(float(v))))
+            else:
+                out.append('<c r="%s" t="inlineStr"><is><t>%s</t></is></c>' % (ref, escape(str(v))))
+        out.append("</row>")
+    out.append("</sheetData></worksheet>")
+    return "".join(out)
+
+
+def write_corr_workbook(path, dates, names, mats):
+    """correlations.xlsx as calccorr lays it out (:1140-1161): sheet 1 ("Sheet1") = header row of the labels from B1 and
+    one row per date (A: the date, B..: the LAST row of its matrix -- the forecast's correlations); then one sheet
+    "yyyy_mm" per date holding the labelled matrix at A1 (corner cell: the date).  mats[i]: (NC, NC) array of dates[i]."""
+    import zipfile
+    names = list(names)
+    sheets = [("Sheet1", {})]
+    first = sheets[0][1]
+    for c, nm in enumerate(names):
+        first[(0, c + 1)] = nm
+    for i, (d, m) in enumerate(zip(dates, mats)):
+        d = str(d)
+        m = np.asarray(m)
+        first[(i + 1, 0)] = d
+        for c in range(len(names)):
+            first[(i + 1, c + 1)] = m[-1, c]
+        cells = {(0, 0): d}
+        for c, nm in enumerate(names):
+            cells[(0, c + 1)] = nm
+            cells[(c + 1, 0)] = nm
+        for r in range(len(names)):
+            for c in range(len(names)):
+                cells[(r + 1, c + 1)] = m[r, c]
+        sheets.append((d[0:4] + "_" + d[5:7], cells))
+    ct = ['<?xml version="1.0" encoding="UTF-8" standalone="yes"?>\n<Types xmlns="http://schemas.openxmlformats.org/package/2006/content-types">'
+          '<Default Extension="rels" ContentType="application/vnd.openxmlformats-package.relationships+xml"/>'
+          '<Default Extension="xml" ContentType="application/xml"/>'
+          '<Override PartName="/xl/workbook.xml" ContentType="application/vnd.openxmlformats-officedocument.spreadsheetml.sheet.main+xml"/>']
+    wb = ['<?xml version="1.0" encoding="UTF-8" standalone="yes"?>\n<workbook xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main" '
+          'xmlns:r="http://schemas.openxmlformats.org/officeDocument/2006/relationships"><sheets>']
+    rel = ['<?xml version="1.0" encoding="UTF-8" standalone="yes"?>\n<Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">']
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+        for i, (nm, cells) in enumerate(sheets, 1):
+            ct.append('<Override PartName="/xl/worksheets/sheet%d.xml" ContentType="application/vnd.openxmlformats-officedocument.spreadsheetml.worksheet+xml"/>' % i)
+            wb.append('<sheet name="%s" sheetId="%d" r:id="rId%d"/>' % (nm, i, i))
+            rel.append('<Relationship Id="rId%d" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/worksheet" Target="worksheets/sheet%d.xml"/>' % (i, i))
+            z.writestr("xl/worksheets/sheet%d.xml" % i, _xlsx_sheet(cells))
+        z.writestr("[Content_Types].xml", "".join(ct) + "</Types>")
+        z.writestr("_rels/.rels", '<?xml version="1.0" encoding="UTF-8" standalone="yes"?>\n<Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">'
+                   '<Relationship Id="rId1" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/officeDocument" Target="xl/workbook.xml"/></Relationships>')
+        z.writestr("xl/workbook.xml", "".join(wb) + "</sheets></workbook>")
+        z.writestr("xl/_rels/workbook.xml.rels", "".join(rel) + "</Relationships>")
+    return path
+
+
+def _corr_from_files(datadir, date):
+    """One date's labelled matrix from its five per-draw files, as calccorr reads them (:1100-1125)."""
+    cols, names = [], []
+    for stem, sym in (("filtered_means_", "μ"), ("filtered_variances_", "σ"), ("filtered_state_probs_", "π"),
+                      ("filtered_trans_probs_", None), ("forecasts_", None)):
+        header, rows = _read_csv(os.path.join(datadir, stem + date + ".csv"))
+        data = np.array([[float(x) for x in r[1:]] for r in rows]).T
+        hn = header[1:]
+        if stem == "forecasts_":
+            data, hn = data[:1], hn[:1]               # df4[!, [2]]: the first forecast column only (:1122)
+        cols.append(data)
+        names += [h.replace("state_", sym) if sym else h for h in hn]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return names, np.corrcoef(np.concatenate(cols))
+
+
+def calccorr(datadir, startyear=1980, endyear=2018, startmonth=1, endmonth=2, result=None):
+    """calccorr(datadir; startyear, endyear, startmonth, endmonth) (src/Hmc.jl:1094-1163): `correlations.xlsx` under
+    datadir for the months from (startyear, startmonth) up to but excluding (endyear, endmonth).
+
+    result=None: as upstream, every month's five per-draw files `filtered_*_<yyyy-mm>-01.csv` / `forecasts_<...>.csv` are
+    read back and correlated on the host.  result = a BatchResult of estimatewindows(..., corr=True): the matrices were
+    accumulated on the device while the draws were in HBM -- no per-draw file is read (or needs to exist); every month
+    of the range must be one of the result's end dates.  Returns (path, dates, names, matrices)."""
+    dates = []
+    year, month = int(startyear), int(startmonth)
+    while not (year == endyear and month == endmonth):
+        dates.append("%04d-%02d-01" % (year, month))
+        month += 1
+        if month > 12:
+            month, year = 1, year + 1
+        if year > endyear + 1:
+            raise ValueError("the month range never reaches (endyear, endmonth)")
+    if not dates:
+        raise ValueError("empty month range (upstream fails on data[1] here, src/Hmc.jl:1155)")
+    mats, names = [], None
+    if result is None:
+        for d in dates:
+            names, m = _corr_from_files(datadir, d)
+            mats.append(m)
+    else:
+        if getattr(result, "corr", None) is None:
+            raise ValueError("result carries no correlation matrices (estimatewindows(..., corr=True))")
+        by_date = {str(enddate(o)): w for w, o in enumerate(result.opts)}
+        o0 = result.opts[0]
+        names = corrnames(o0.D, o0.horizons)
+        for d in dates:
+            if d not in by_date:
+                raise ValueError("no window ends on %s" % d)
+            mats.append(result.corr[by_date[d]])
+    os.makedirs(datadir, exist_ok=True)
+    path = write_corr_workbook(os.path.join(datadir, "correlations.xlsx"), dates, names, mats)
+    return path, dates, names, mats

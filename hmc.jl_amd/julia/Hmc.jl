@@ -14,7 +14,8 @@
 # hmcg_estimate_batch_multi; `window_ids` pins the RNG streams), estimatesignals! (signal Monte-Carlo path incl. signals
 # past the end date), saveresults with and without signals -- written by the library's native CSV writer
 # (hmcg_save_results_csv: CSV.jl 0.5.16 float text, 250k rows x 5 files in under a second).  Not wired here (available
-# through the C ABI and the Python host layer): checkpoint/resume, the smoothed-probability output.  runaggregate /
+# through the C ABI and the Python host layer): checkpoint/resume, the smoothed-probability output, the correlation
+# workbook writer (calccorr's matrices themselves: estimatewindows(...; corr=true)).  runaggregate /
 # calcdispersion of the reference work unchanged on the files written here (same names, columns and float text).
 #
 # Reference lines mirrored: estopt src/Hmc.jl:17-73, accessors :85-107, makedate :573-582,
@@ -73,11 +74,12 @@ struct hmcg_extras
     end_pos::Ptr{Int32}
     pi_smooth_mean::Ptr{Float64}
     pi_filter_mean::Ptr{Float64}
+    corr::Ptr{Float64}
 end
 const HMCG_MAXTAIL = 32
 const HMCG_MAXDEV = 16
 
-struct hmcg_timing                    # include/hmcg.h (ABI 103)
+struct hmcg_timing                    # include/hmcg.h (ABI 104)
     kernel_ms::Float64
     launches::Int32
     threads_per_window::Int32
@@ -165,9 +167,12 @@ partitions the windows over those GPUs inside the library (hmcg_estimate_batch_m
 results gathered into these arrays; bit-identical to the single-device call).  `window_ids` (UInt32 per window) pins
 the RNG streams.  Returns
 `(samples::Vector{NamedTuple}, summary::Matrix{Float64}, status::Vector{Int32})`; `summary[:, w]` holds the
-means of the 5-digit-rounded draws in the order mu | sigma | pib_end | A(:) | forecasts.
+means of the 5-digit-rounded draws in the order mu | sigma | pib_end | A(:) | forecasts.  `corr=true` adds a fourth
+value, `ρ[:, :, w]`: the correlation matrix calccorr (src/Hmc.jl:1094-1163) computes per end date from the per-draw CSV
+files, accumulated on the device (extras.corr; labels: `corrnames`); with `keepdraws=false` no draw leaves the GPU.
 """
-function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothing, keepdraws::Bool=true, window_ids=nothing)
+function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothing, keepdraws::Bool=true, window_ids=nothing,
+                         corr::Bool=false)
     foreach(_check_live, opts)
     o = opts[1]
     W = length(opts); K = o.D; H = length(o.horizons); nrun = o.Nrun
@@ -191,13 +196,15 @@ function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothin
     fc = keepdraws ? Array{Float64}(undef, nrun, 2H, W) : Float64[]
     summary = Array{Float64}(undef, NS, W)
     status = zeros(Int32, W)
+    NC = 3K + K * K + 1
+    ρ = corr ? Array{Float64}(undef, NC, NC, W) : Float64[]      # symmetric: C row-major == Julia column-major
     p(a) = isempty(a) ? Ptr{Float64}(C_NULL) : pointer(a)
     wids = window_ids === nothing ? UInt32[] : Vector{UInt32}(window_ids)
     ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
                          isempty(wids) ? Ptr{UInt32}(C_NULL) : pointer(wids), C_NULL, C_NULL, C_NULL, C_NULL, Int32(0), Int32(0),
-                         C_NULL, C_NULL, C_NULL))
+                         C_NULL, C_NULL, C_NULL, corr ? pointer(ρ) : Ptr{Float64}(C_NULL)))
     yr = H > 0 ? pointer(yreal) : Ptr{Float64}(C_NULL)
-    rc = GC.@preserve Y Ts yreal μ σ A πe fc summary status wids begin
+    rc = GC.@preserve Y Ts yreal μ σ A πe fc summary status wids ρ begin
         if devices === nothing
             ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
                   (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
@@ -220,8 +227,17 @@ function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothin
                             A = A[:, :, :, w], forecasts = fc[:, :, w], obsdates = fill(enddate(x), nrun)))
         end
     end
-    return samples, summary, status
+    return corr ? (samples, summary, status, ρ) : (samples, summary, status)
 end
+
+"""
+    corrnames(K, horizons) -> Vector{String}
+
+Row / column labels of the matrices `estimatewindows(...; corr=true)` returns: what calccorr (src/Hmc.jl:1094-1163)
+derives from the CSV headers -- μ1..K, σ1..K, π1..K, trans_i_j (i fastest), forecast_<first horizon>.
+"""
+corrnames(K::Integer, horizons) = vcat(["μ$i" for i in 1:K], ["σ$i" for i in 1:K], ["π$i" for i in 1:K],
+                                       vec(["trans_$(i)_$(j)" for i in 1:K, j in 1:K]), ["forecast_$(horizons[1])"])
 
 """
     estimatemodel(opt) -> (μ, σ, πb, A, forecasts, obsdates)      (src/Hmc.jl:850-865)
@@ -249,7 +265,7 @@ function _signal_call(opt::estopt, burnin, nrun, n_samples, σsignal, κ, α, ν
     rc = GC.@preserve Y T yreal μ σ A πe fc st sig sv ssig sigvals ep begin
         ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
                              pointer(sig), pointer(sv), pointer(ssig), pointer(sigvals), Int32(max(nsave, 1)), Int32(0),
-                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL, C_NULL))
+                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL, C_NULL, C_NULL))
         ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
               (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{hmcg_extras}, Ptr{Cvoid}),

@@ -17,7 +17,8 @@ def _expected(res, w, K):
     cols = [res["mu"][w, k] for k in range(K)] + [res["sig2"][w, k] for k in range(K)] + [res["pi_end"][w, k] for k in range(K)]
     cols += [res["A"][w].reshape(K * K, -1)[q] for q in range(K * K)]
     cols.append(res["fcast"][w, 0])
-    return np.corrcoef(_round5(np.stack(cols)))
+    with np.errstate(invalid="ignore", divide="ignore"):       # a constant column: NaN, as Statistics.cor gives
+        return np.corrcoef(_round5(np.stack(cols)))
 
 
 @pytest.mark.parametrize("K,T,nrun,W", [(3, 400, 1500, 5), (2, 300, 700, 3), (4, 250, 600, 2), (8, 600, 300, 2)])
@@ -73,3 +74,29 @@ def test_corr_skipped_window_is_nan():
     res = _lib.estimate_batch_host(Y, Tw, 3, 10, 200, horizons=(12,), yreal=fut[:, 11:12], want_corr=True)
     assert res["status"][1] != 0 and np.isnan(res["corr"][1]).all()
     assert np.isfinite(res["corr"][0]).all() and np.isfinite(res["corr"][2]).all()
+
+
+def test_calccorr_device_matrices_equal_the_file_route(inflation, tmp_path):
+    """code/run_hmm.jl's windows for three consecutive end dates: the workbook calccorr builds from the per-draw files
+    (upstream's route) and the one built from the device's matrices (no file read) agree cell by cell."""
+    import datetime as dt
+    from hmc_jl_amd import hmc
+    y, dates = inflation
+    dd = [dt.date.fromisoformat(d) for d in dates]
+    ends = [200, 201, 202]
+    res = hmc.estimatewindows(y, dd, ends, horizons=[12], D=3, burnin=300, Nrun=3000, series="official", keep_draws=True, corr=True)
+    assert (res.status == 0).all() and res.corr.shape == (3, 19, 19)
+    for w in range(3):
+        hmc.saveresults(res.samples(w), res.opts[w], str(tmp_path))
+    d0, d1 = dd[ends[0] - 1], dd[ends[-1]]           # half-open month range
+    pf, dates_f, names_f, mats_f = hmc.calccorr(str(tmp_path), d0.year, d1.year, d0.month, d1.month)
+    files = open(pf, "rb").read()
+    pd_, dates_d, names_d, mats_d = hmc.calccorr(str(tmp_path / "dev"), d0.year, d1.year, d0.month, d1.month, result=res)
+    assert dates_f == dates_d == [str(dd[e - 1]) for e in ends] and names_f == names_d
+    for a, b in zip(mats_f, mats_d):
+        ok = np.isfinite(a)
+        assert np.array_equal(ok, np.isfinite(b)) and np.abs(a[ok] - b[ok]).max() < 1e-10
+    assert len(files) > 1000 and len(open(pd_, "rb").read()) > 1000
+    # without the draws: same matrices, nothing but summaries and correlations crosses PCIe
+    lean = hmc.estimatewindows(y, dd, ends, horizons=[12], D=3, burnin=300, Nrun=3000, series="official", keep_draws=False, corr=True)
+    assert np.array_equal(lean.corr, res.corr, equal_nan=True)
