@@ -617,59 +617,94 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         // ---- replay of the normalised recursion (:413-432), fused with the state maps of update_X (:459-484):
         // at step t the running sums over r of pif[t-1,r] A[r,s] are both pif[t,s]/f and the cumulative
         // weights of the draw X[t-1] | X[t] = s; the eps() guard is pif[t,s] itself.
-        for (int l = 0; l < L; ++l) {
-            asm volatile("" ::: "memory");       // as above: A stays in LDS
-            const int t = t0 + l;
-            double fv[K];
-            pdfs(th, ylds[t], t < T, fv);
-            const double u = t >= 1 ? uxs[t - 1] : 0.0;
-            double nv[K], total = 0.0;
-            uint32_t mok = 0;
+        // (The emission parameters sit in registers for all L steps; the transition matrix stays in LDS, a column at a
+        //  time -- 64 more live doubles were measured to land in AGPRs and cost four times the instructions of the reads.)
+        {
+            double mu_r[K], isd_r[K], coef_r[K];
 #pragma unroll
-            for (int s = 0; s < K; ++s) {
-                double a[K], cum[K];
+            for (int s = 0; s < K; ++s) { mu_r[s] = th.mu[s]; isd_r[s] = th.isd[s]; coef_r[s] = th.coef[s]; }
+            const bool want_pif = (last_sweep || do_smooth) && p.pif_final != nullptr;
+            for (int l = 0; l < L; ++l) {
+                asm volatile("" ::: "memory");       // as above: A stays in LDS
+                const int t = t0 + l;
+                const double yv = ylds[t];
+                const double u = uxs[t >= 1 ? t - 1 : 0];
+                // pdfs of y[t], scaled by the power of two that brings the largest into [0.5,1)
+                double fv[K];
+                unsigned hm = 0;
 #pragma unroll
-                for (int k = 0; k < K; ++k) a[k] = th.At[s][k];
-                double acc = 0.0;
+                for (int s = 0; s < K; ++s) {
+                    const double z = (yv - mu_r[s]) * isd_r[s];
+                    fv[s] = exp_tab(-0.5 * (z * z), sh.exptab) * coef_r[s];
+                    hm = max(hm, (unsigned)__double2hiint(fv[s]));
+                }
+                {
+                    const int e = 1022 - (int)(hm >> 20);
 #pragma unroll
-                for (int r = 0; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[r] = acc; }
-                const double thr = u * acc;
-                int idx = 0;
+                    for (int s = 0; s < K; ++s) fv[s] = ldexp(fv[s], e);
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hm < 0x01A56E1Fu) != 0ull, 0)) {      // rare, wave-uniform
+                    if (hm < 0x01A56E1Fu) {
+                        if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
-                for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
-                mok |= (uint32_t)idx << (4 * s);
-                nv[s] = acc * fv[s];
-                total += nv[s];
-            }
-            if (!(total > 0.0)) {
-                if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+                        for (int s = 0; s < K; ++s) fv[s] = 1.0;
+                    }
+                }
+                double nv[K], total = 0.0;
+                uint32_t mok = 0;
 #pragma unroll
-                for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
-                total = 1.0;
-            }
-            const double inv = rcp_fast(total);
-            int idx_uni = 0;
-            {
-                double cp = 0.0;
+                for (int s = 0; s < K; ++s) {
+                    double a[K], cum[K];
 #pragma unroll
-                for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx_uni += (cp <= u) ? 1 : 0; }
-            }
-            uint32_t m = 0;
+                    for (int k = 0; k < K; ++k) a[k] = th.At[s][k];
+                    double acc = av[0] * a[0];
+                    cum[0] = acc;
 #pragma unroll
-            for (int s = 0; s < K; ++s) {
-                av[s] = nv[s] * inv;                                        // pif[t,s]
-                const uint32_t idx = (av[s] > EPS64) ? ((mok >> (4 * s)) & 15u) : (uint32_t)idx_uni;   // :472-480
-                m |= idx << (4 * s);
-            }
-            if (t >= 1) maps[t - 1] = m;                                     // g_{t-1}; entries at/after T-1 are overridden below
-            if (t == T - 1) {
+                    for (int r = 1; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[r] = acc; }
+                    const double thr = u * acc;
+                    int idx = 0;
 #pragma unroll
-                for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
-                sh.ulast = uxs[T - 1];
-            }
-            if ((last_sweep || do_smooth) && p.pif_final && t < T) {
+                    for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
+                    mok |= (uint32_t)idx << (4 * s);
+                    nv[s] = acc * fv[s];
+                    total += nv[s];
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(total > 0.0)) != 0ull, 0)) {
+                    if (!(total > 0.0)) {
+                        if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
 #pragma unroll
-                for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t) * K + s] = av[s];
+                        for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
+                        total = 1.0;
+                    }
+                }
+                const double inv = rcp_fast(total);
+                int idx_uni = 0;
+                {
+                    double cp = 0.0;
+#pragma unroll
+                    for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx_uni += (cp <= u) ? 1 : 0; }
+                }
+                // guards (:472-480): the entries whose pif[t,s] fails eps() take the uniform draw -- built as a nibble
+                // mask so that the common case (no failure in the wave) costs one select per state
+                uint32_t fail = 0;
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    av[s] = nv[s] * inv;                                        // pif[t,s]
+                    fail |= (av[s] > EPS64) ? 0u : (0xFu << (4 * s));
+                }
+                const uint32_t m = (mok & ~fail) | ((uint32_t)idx_uni * 0x11111111u & fail);
+                if (t >= 1) maps[t - 1] = m;                                     // g_{t-1}; entries at/after T-1 are overridden below
+                if (t == T - 1) {
+#pragma unroll
+                    for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
+                    sh.ulast = uxs[T - 1];
+                }
+                if (want_pif) {
+                    if (t < T) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t) * K + s] = av[s];
+                    }
+                }
             }
         }
         if constexpr (SM) {
