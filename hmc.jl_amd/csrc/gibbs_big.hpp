@@ -373,22 +373,25 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     if (p.sweep_begin < p.sweep_end && shadow_wave == 0) job_prep(p.sweep_begin);
 
     // pdfs of one observation, scaled by the power of two that brings the largest into [0.5,1)
-    auto pdfs = [&](const ThetaBufBig<K>& th, double yv, bool valid, double (&fv)[K]) {
+    auto pdfs = [&](const ThetaBufBig<K>& th, double yv, bool valid, double (&fv)[K]) __attribute__((always_inline)) {
         unsigned hm = 0;
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const double z = (yv - th.mu[s]) * th.isd[s];
-            fv[s] = exp_tab(-0.5 * (z * z), sh.exptab) * th.coef[s];
+            fv[s] = exp_tab(-(z * z), sh.exptab) * th.coef[s];
             hm = max(hm, (unsigned)__double2hiint(fv[s]));
         }
-        if (hm < 0x01A56E1Fu) {
-            if (valid) st |= HMCG_ST_EMIS_UNDERFLOW;
-#pragma unroll
-            for (int s = 0; s < K; ++s) fv[s] = 1.0;
-        } else {
+        {
             const int e = 1022 - (int)(hm >> 20);
 #pragma unroll
             for (int s = 0; s < K; ++s) fv[s] = ldexp(fv[s], e);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hm < 0x01A56E1Fu) != 0ull, 0)) {      // rare, wave-uniform branch
+            if (hm < 0x01A56E1Fu) {
+                if (valid) st |= HMCG_ST_EMIS_UNDERFLOW;
+#pragma unroll
+                for (int s = 0; s < K; ++s) fv[s] = 1.0;
+            }
         }
     };
 
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     const double isd = rcp_fast(sd);
                     th.mu[role] = m + sdev * rb.z[role];
                     th.sig2[role] = sig2;
-                    th.isd[role] = isd;
+                    th.isd[role] = isd * 0.70710678118654752440;                 // 1/(sd sqrt 2): exp(-z^2) = exp(-((y-mu)/sd)^2 / 2)
                     th.coef[role] = INVSQRT2PI * isd;
                     th.rho[role] = rb.rho[role];
                 }
@@ -551,7 +554,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             for (; l + 1 < L; l += 2) {
                 mstep(Q, N, l);
                 mstep(N, Q, l + 1);
-                rescale_pow2<KK>(Q);
+                // (every step's largest pdf lies in [0.5,1): four steps between two exact power-of-two rescalings are far
+                //  inside the fp64 range)
+                if (l & 2) rescale_pow2<KK>(Q);
             }
             if (l < L) {
                 mstep(Q, N, l);
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
                     const double z = (yv - mu_r[s]) * isd_r[s];
-                    fv[s] = exp_tab(-0.5 * (z * z), sh.exptab) * coef_r[s];
+                    fv[s] = exp_tab(-(z * z), sh.exptab) * coef_r[s];
                     hm = max(hm, (unsigned)__double2hiint(fv[s]));
                 }
                 {
