@@ -120,7 +120,7 @@ def shape_record(name, K_, lens, draws, reps=3, device=0):
 
 def c_caller_record(Y, Tw, yreal, reps=20):
     """The same workload from a plain-C caller (tests/cdriver, no Python in the process, buffers allocated once and reused --
-    what a Julia `ccall` site does): mean wall time per hmcg_estimate_batch call."""
+    what a Julia `ccall` site does): median wall time per hmcg_estimate_batch call (mean, min and max beside it)."""
     import struct
     import tempfile
     import numpy as np
@@ -140,12 +140,13 @@ def c_caller_record(Y, Tw, yreal, reps=20):
         r = subprocess.run([drv, req, os.path.join(tmp, "resp.bin")], capture_output=True, text=True, timeout=300,
                            env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
     import re
-    m = re.search(r"cdriver bench: ([0-9.]+) ms per call.*?(\d+) launches, kernels ([0-9.]+) ms, call ([0-9.]+) ms", r.stdout)
+    m = re.search(r"cdriver bench: ([0-9.]+) ms per call.*?(\d+) launches, kernels ([0-9.]+) ms, call ([0-9.]+) ms; median of calls, mean ([0-9.]+) min ([0-9.]+) max ([0-9.]+)", r.stdout)
     if r.returncode != 0 or not m:
         return {"error": (r.stdout + r.stderr)[-300:]}
     ms = float(m.group(1))
     return {"ms_per_call": ms, "value": W * DRAWS / (ms * 1e-3), "unit": "Gibbs draws/s", "launches": int(m.group(2)),
-            "kernel_ms_sum_timed_call": float(m.group(3)), "calls": reps}
+            "kernel_ms_sum_timed_call": float(m.group(3)), "calls": reps, "statistic": "median of the per-call wall times",
+            "mean_ms": float(m.group(5)), "min_ms": float(m.group(6)), "max_ms": float(m.group(7))}
 
 
 def end_to_end_record(Y, Tw, yreal, reps=7):

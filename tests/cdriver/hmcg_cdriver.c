@@ -73,12 +73,23 @@ int main(int argc, char** argv)
             rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, NULL);
             if (rc) { fprintf(stderr, "libhmcgibbs rc=%d: %s\n", rc, hmcg_last_error()); return 5; }
         }
-        const double t0 = now_ms();
-        for (int i = 0; i < reps; ++i) rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, NULL);
-        const double per = (now_ms() - t0) / reps;
+        /* per-call wall times; the median is reported (a host thread that gets descheduled once costs a mean 10 %) */
+        double* tc = calloc((size_t)reps, 8);
+        double sum = 0.0;
+        for (int i = 0; i < reps; ++i) {
+            const double t0 = now_ms();
+            rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, NULL);
+            tc[i] = now_ms() - t0;
+            sum += tc[i];
+        }
+        for (int i = 1; i < reps; ++i)                          /* insertion sort */
+            for (int j = i; j > 0 && tc[j - 1] > tc[j]; --j) { const double x = tc[j]; tc[j] = tc[j - 1]; tc[j - 1] = x; }
+        const double per = reps & 1 ? tc[reps / 2] : 0.5 * (tc[reps / 2 - 1] + tc[reps / 2]);
+        const double mean = sum / reps, tmin = tc[0], tmax = tc[reps - 1];
         rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, tm);
         printf("cdriver bench: %.4f ms per call over %d calls (W=%d K=%d T<=%d draws=%d, all per-draw outputs to host); "
-               "timed call: %d launches, kernels %.3f ms, call %.3f ms\n", per, reps, W, K, ldY, nrun, tm[0].launches, tm[0].kernel_ms, tm[0].call_ms);
+               "timed call: %d launches, kernels %.3f ms, call %.3f ms; median of calls, mean %.4f min %.4f max %.4f\n", per, reps, W, K, ldY,
+               nrun, tm[0].launches, tm[0].kernel_ms, tm[0].call_ms, mean, tmin, tmax);
         hmcg_shutdown();
         return rc ? 5 : 0;
     }
