@@ -72,6 +72,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     double* const uxs = dyn_lds + cap;                              // [cap] uniforms of the running sweep
     uint32_t* const maps = reinterpret_cast<uint32_t*>(dyn_lds + 2 * (size_t)cap);   // [cap] state maps g_t
     uint8_t* const xs = reinterpret_cast<uint8_t*>(maps + cap);     // [cap + 8] states
+    // HBM scratch of this thread's per-step pdfs, [L][K] with the thread index fastest (p.fscr is [W][L][K][NT])
+    double* const fscr = p.fscr + (size_t)blockIdx.x * L * K * NT + threadIdx.x;
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,6 +406,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         rng.sweep = (uint32_t)sweep;
         const int par = sweep & 1;
         ThetaBufBig<K>& th = sh.th[par];
+        // the transposed transition matrix through an opaque LDS pointer: all 64 reads of a step are then immediate
+        // offsets from ONE address register (from the struct's own base every read beyond 2 KB costs an s_add + v_mov)
+        typedef __attribute__((address_space(3))) const double lds_cdouble;
+        lds_cdouble* Atp = (lds_cdouble*)&th.At[0][0];
+        asm volatile("" : "+v"(Atp));
         const bool last_sweep = sweep + 1 == p.sweep_end;
         __syncthreads();                                                     // Ba
         STAMP(0);
@@ -523,11 +530,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
             double fv[K];
             pdfs(th, ylds[t0 + l], t0 + l < T, fv);
+            // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
+            // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
+#pragma unroll
+            for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 double a[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) a[k] = th.At[s][k];
+                for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
 #pragma unroll
                 for (int r = 0; r < K; ++r) {
                     double acc = in[r * K] * a[0];
@@ -546,6 +557,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                     for (int i = 0; i < KK; ++i) Q[i] = N[i];
                     if (l & 1) rescale_pow2<KK>(Q);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = 1.0;
                 }
             }
             rescale_pow2<KK>(Q);
@@ -622,38 +636,23 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         // ---- replay of the normalised recursion (:413-432), fused with the state maps of update_X (:459-484):
         // at step t the running sums over r of pif[t-1,r] A[r,s] are both pif[t,s]/f and the cumulative
         // weights of the draw X[t-1] | X[t] = s; the eps() guard is pif[t,s] itself.
-        // (The emission parameters sit in registers for all L steps; the transition matrix stays in LDS, a column at a
+        // (The pdfs come back from the scratch the product phase filled; the transition matrix stays in LDS, a column at a
         //  time -- 64 more live doubles were measured to land in AGPRs and cost four times the instructions of the reads.)
         {
-            double mu_r[K], isd_r[K], coef_r[K];
-#pragma unroll
-            for (int s = 0; s < K; ++s) { mu_r[s] = th.mu[s]; isd_r[s] = th.isd[s]; coef_r[s] = th.coef[s]; }
             const bool want_pif = (last_sweep || do_smooth) && p.pif_final != nullptr;
+            double fnext[K];                     // pdfs of the step ahead, on their way from the scratch
+#pragma unroll
+            for (int s = 0; s < K; ++s) fnext[s] = fscr[(size_t)s * NT];
             for (int l = 0; l < L; ++l) {
                 asm volatile("" ::: "memory");       // as above: A stays in LDS
                 const int t = t0 + l;
-                const double yv = ylds[t];
                 const double u = uxs[t >= 1 ? t - 1 : 0];
-                // pdfs of y[t], scaled by the power of two that brings the largest into [0.5,1)
                 double fv[K];
-                unsigned hm = 0;
 #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    const double z = (yv - mu_r[s]) * isd_r[s];
-                    fv[s] = exp_tab(-(z * z), sh.exptab) * coef_r[s];
-                    hm = max(hm, (unsigned)__double2hiint(fv[s]));
-                }
-                {
-                    const int e = 1022 - (int)(hm >> 20);
+                for (int s = 0; s < K; ++s) fv[s] = fnext[s];
+                if (l + 1 < L) {
 #pragma unroll
-                    for (int s = 0; s < K; ++s) fv[s] = ldexp(fv[s], e);
-                }
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hm < 0x01A56E1Fu) != 0ull, 0)) {      // rare, wave-uniform
-                    if (hm < 0x01A56E1Fu) {
-                        if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
-#pragma unroll
-                        for (int s = 0; s < K; ++s) fv[s] = 1.0;
-                    }
+                    for (int s = 0; s < K; ++s) fnext[s] = fscr[((size_t)(l + 1) * K + s) * NT];
                 }
                 double nv[K], total = 0.0;
                 uint32_t mok = 0;
@@ -661,7 +660,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 for (int s = 0; s < K; ++s) {
                     double a[K], cum[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) a[k] = th.At[s][k];
+                    for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
                     double acc = av[0] * a[0];
                     cum[0] = acc;
 #pragma unroll

@@ -82,6 +82,9 @@ struct KernelParams {
     double* pi_smooth_mean;
     // the same running sum for the FILTERED probabilities pif[t,:] (sorted labels), [W][ldY][K]; SMOOTH variants
     double* pi_filter_mean;
+    // LDS-resident kernel (gibbs_big.hpp) only: scratch that hands each step's K pdfs from the product phase to the replay,
+    // [W][L][K][NT] (thread index fastest: coalesced); library-owned
+    double* fscr;
 };
 
 // index of the kept draw produced by global sweep g, or -1 during burn-in

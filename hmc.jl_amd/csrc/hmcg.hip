@@ -97,6 +97,7 @@ struct DeviceCtx {
     int cu_count = 0;
     Arena dev, pin;
     Arena mom;                     // device entry: the draw-moment tables behind extras.corr
+    Arena scr;                     // device entry: the LDS-resident kernel's pdf scratch
 };
 DeviceCtx g_ctx[HMCG_MAXDEV];
 std::mutex g_init_mu;
@@ -148,6 +149,7 @@ void destroy_context(DeviceCtx& c)
     c.dev.release();
     c.pin.release();
     c.mom.release();
+    c.scr.release();
     c.stream = c.copy = nullptr;
     c.ready = false;
     c.device = -1;
@@ -211,6 +213,8 @@ struct Plan {
     int NT() const { return v ? v->NT : bv->NT; }
     int L() const { return v ? v->L : bigL; }
     int NH() const { return v ? v->NH : 0; }
+    // LDS-resident kernel: per-step pdfs handed from the product phase to the replay, [W][L][K][NT] doubles
+    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)K * (size_t)bv->NT : 0; }
     const void* fptr() const { return v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn); }
 };
 
@@ -390,7 +394,13 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
     p.nd_ld = p.nd; p.draw_off = 0;
 
     if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
-    if (pl.bv) HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
+    if (pl.bv) {
+        HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
+        const size_t sbytes = pl.scratch_bytes(cfg->W, cfg->K);
+        if (c.scr.cap < sbytes) HIP_TRY(hipStreamSynchronize(stream));        // growing the scratch frees the old one
+        if (c.scr.ensure(sbytes)) { set_err("workspace allocation failed (%zu B device)", sbytes); return HMCG_E_NOMEM; }
+        p.fscr = reinterpret_cast<double*>(c.scr.base);
+    }
     if (timing) HIP_TRY(hipEventRecord(c.ev0, stream));
 #ifdef HMCG_STAMPS
     const size_t ndbg = (size_t)cfg->W * (pl.NT() / 64 + pl.NH()) * HMCG_NSTAMP;
@@ -544,6 +554,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const size_t o_dep = (ex && ex->end_pos) ? LD.add(4 * N) : 0, o_dss = (ex && ex->sigma_signal) ? LD.add(8 * N) : 0;
     const size_t o_dsv = want_sv ? LD.add(8 * N * nsv) : 0;
     const size_t o_dmom = want_corr ? LD.add(8 * N * mom_stride) : 0, o_dcorr = want_corr ? LD.add(8 * N * NCC * NCC) : 0;
+    const size_t o_dfs = pl.bv ? LD.add(pl.scratch_bytes(n, cfg->K)) : 0;
     // pinned staging: inputs, small outputs, chunk ring, one-off big extras
     const size_t o_pY = LP.add(8 * N * ld), o_pT = LP.add(4 * N), o_pst = LP.add(4 * N), o_pwid = LP.add(4 * N);
     const size_t o_pyr = (h.yreal && H) ? LP.add(8 * N * H) : 0;
@@ -633,6 +644,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     hmcg::KernelParams base = base_params(cfg, n, DP(double, o_dY), DP(int32_t, o_dT), (h.yreal && H) ? DP(double, o_dyr) : nullptr,
                                           DP(int32_t, o_dst), &dex, pl.use_sig);
     base.summary = h.summary ? DP(double, o_dsum) : nullptr;
+    if (pl.bv) base.fscr = DP(double, o_dfs);
     if (pl.bv) HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
 
     // ---- the chunk pipeline ----
