@@ -55,6 +55,24 @@ struct BigShared {
 // large-K / long-window counterpart of the SMOOTH variants of gibbs_device.hpp.  The filtered probabilities of the
 // running sweep pass through p.pif_final (written by the forward replay, read back by the backward pass), the running
 // sums live in HBM (T x K doubles per window do not fit on the chip: this variant genuinely streams them).
+// #{i < N : c[i] <= thr} for a non-decreasing c (cumulative sums of non-negative terms), N <= 7: a three-level bisection
+// -- 3 compares and 8 selects instead of N compare + add-with-carry pairs.  The same predicate as the linear count
+// (Categorical's CDF scan, src/Hmc.jl:481), so the draws do not change.
+template <int N>
+__device__ __forceinline__ int count_le_sorted(const double (&c)[N + 1], double thr)
+{
+    static_assert(N >= 1 && N <= 7, "three levels");
+    constexpr double INF = __builtin_huge_val();
+    auto C = [&](int i) __attribute__((always_inline)) { return i < N ? c[i < N ? i : 0] : INF; };
+    const bool b1 = C(3) <= thr;
+    const double m2 = b1 ? C(5) : C(1);
+    const double lo3 = b1 ? C(4) : C(0), hi3 = b1 ? C(6) : C(2);
+    const bool b2 = m2 <= thr;
+    const double m3 = b2 ? hi3 : lo3;
+    const bool b3 = m3 <= thr;
+    return (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);
+}
+
 template <int K, int NT, bool SM = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
@@ -666,9 +684,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                     for (int r = 1; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[r] = acc; }
                     const double thr = u * acc;
-                    int idx = 0;
-#pragma unroll
-                    for (int r = 0; r < K - 1; ++r) idx += (cum[r] <= thr) ? 1 : 0;
+                    const int idx = count_le_sorted<K - 1>(cum, thr);
                     mok |= (uint32_t)idx << (4 * s);
                     nv[s] = acc * fv[s];
                     total += nv[s];
