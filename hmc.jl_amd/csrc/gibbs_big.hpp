@@ -40,7 +40,7 @@ struct BigShared {
     RngBuf<K> rb[2];
     double gval[NG];              // gamma variates of the running parameter phase
     double wtot[NW][KK];
-    uint32_t wmap[NW];
+    uint32_t wmap[NW][2];         // per-wave composed state map, byte-per-entry in two words
     double ulast;
     double bred[NW];
     double med[2];
@@ -55,6 +55,21 @@ struct BigShared {
 // large-K / long-window counterpart of the SMOOTH variants of gibbs_device.hpp.  The filtered probabilities of the
 // running sweep pass through p.pif_final (written by the forward replay, read back by the backward pass), the running
 // sums live in HBM (T x K doubles per window do not fit on the chip: this variant genuinely streams them).
+// Byte-per-entry state maps for up to eight states, in two words: entry s is byte s & 3 of (s < 4 ? lo : hi).
+struct ByteMap { uint32_t lo, hi; };
+__device__ __forceinline__ ByteMap bytemap_identity() { return ByteMap{0x03020100u, 0x07060504u}; }
+// (a o b)[s] = a[b[s]]: v_perm_b32's selector values 0..3 take bytes of its second source, 4..7 of its first
+__device__ __forceinline__ ByteMap bytemap_compose(const ByteMap a, const ByteMap b)
+{
+    return ByteMap{__builtin_amdgcn_perm(a.hi, a.lo, b.lo), __builtin_amdgcn_perm(a.hi, a.lo, b.hi)};
+}
+__device__ __forceinline__ uint32_t spread_nibbles(uint32_t x)      // 0x0000dcba -> 0x0d0c0b0a
+{
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    return (x | (x << 4)) & 0x0F0F0F0Fu;
+}
+__device__ __forceinline__ ByteMap bytemap_from_nibbles(uint32_t m) { return ByteMap{spread_nibbles(m & 0xFFFFu), spread_nibbles(m >> 16)}; }
+
 // #{i < N : c[i] <= thr} for a non-decreasing c (cumulative sums of non-negative terms), N <= 7: a three-level bisection
 // -- 3 compares and 8 selects instead of N compare + add-with-carry pairs.  The same predicate as the linear count
 // (Categorical's CDF scan, src/Hmc.jl:481), so the draws do not change.
@@ -836,32 +851,47 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
         }
         // ---- backward sampling: compose this thread's maps, suffix-scan over lanes and waves, apply ----
-        uint32_t G = map_identity<K>();
+        // The maps stay 4-bit in LDS (one word per step); for composing they are widened to a byte per entry in two
+        // words, where (a o b) is two v_perm_b32 -- the selector bytes 0..7 of b pick from the eight bytes {a.hi, a.lo} --
+        // instead of eight shift-mask-shift-or rounds.
+        ByteMap G = bytemap_identity();
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
             uint32_t m = maps[t];
             m = (t == T - 1) ? map_const<K>(xlast) : (t > T - 1 ? map_identity<K>() : m);
             maps[t] = m;
-            G = map_compose<K>(m, G);
+            G = bytemap_compose(bytemap_from_nibbles(m), G);
         }
         STAMP(9);
-        uint32_t Hm = G;
+        ByteMap Hm = G;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t O = __shfl_down(Hm, d, 64);
-            const uint32_t C = map_compose<K>(Hm, O);
-            Hm = (lane + d < 64) ? C : Hm;
+            ByteMap O;
+            O.lo = __shfl_down(Hm.lo, d, 64);
+            O.hi = __shfl_down(Hm.hi, d, 64);
+            const ByteMap C = bytemap_compose(Hm, O);
+            const bool in = lane + d < 64;
+            Hm.lo = in ? C.lo : Hm.lo;
+            Hm.hi = in ? C.hi : Hm.hi;
         }
-        if (lane == 0) sh.wmap[wave] = Hm;
+        if (lane == 0) { sh.wmap[wave][0] = Hm.lo; sh.wmap[wave][1] = Hm.hi; }
         STAMP(10);
         __syncthreads();                                                     // Be
         STAMP(11);
-        uint32_t Rw = map_identity<K>();
+        ByteMap Rw = bytemap_identity();
 #pragma unroll
-        for (int ww = NW - 1; ww >= 1; --ww) Rw = (ww > wave) ? map_compose<K>(sh.wmap[ww], Rw) : Rw;
-        uint32_t Hx = __shfl_down(Hm, 1, 64);
-        if (lane == 63) Hx = map_identity<K>();
-        int sin = map_apply(map_compose<K>(Hx, Rw), 0);
+        for (int ww = NW - 1; ww >= 1; --ww) {
+            ByteMap Wm;
+            Wm.lo = sh.wmap[ww][0]; Wm.hi = sh.wmap[ww][1];
+            const ByteMap C = bytemap_compose(Wm, Rw);
+            Rw.lo = (ww > wave) ? C.lo : Rw.lo;
+            Rw.hi = (ww > wave) ? C.hi : Rw.hi;
+        }
+        ByteMap Hx;
+        Hx.lo = __shfl_down(Hm.lo, 1, 64);
+        Hx.hi = __shfl_down(Hm.hi, 1, 64);
+        if (lane == 63) Hx = bytemap_identity();
+        int sin = (int)(bytemap_compose(Hx, Rw).lo & 0xFFu);               // entry 0 (a constant map below T-1)
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
             if (t < T) { sin = map_apply(maps[t], sin); xs[t] = (uint8_t)sin; }
