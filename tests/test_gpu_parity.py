@@ -448,3 +448,30 @@ def test_gpu_reference_unit_test_truth_recovery(hmclib):
     g = _lib.estimate_batch_host(Y[None, :476], [476], 2, 3000, 1000, (12,), np.array([[Y[487]]]))
     np.testing.assert_allclose(g["mu"][0].mean(axis=1), [-5.0, 4.0], atol=0.3)
     np.testing.assert_allclose(g["sig2"][0].mean(axis=1), [1.0, 0.5], atol=0.5)
+
+
+def test_full_size_cfg4_properties_and_subset_identity(hmclib, oracle):
+    """BASELINE configs[3] at full size (8 states, T=5000, 512 windows; 12 draws instead of 1000): size-independent
+    properties on every window, batching invariance against the same windows run on their own with their global ids (bit
+    for bit -- the pdf scratch, the chunk products and the maps are per window), oracle parity on one window."""
+    W, T, K, n = 512, 5000, 8, 12
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    yreal = fut[:, 11:12]
+    g = _lib.estimate_batch_host(Y, Tw, K, 3, n, (12,), yreal, want_state=True)
+    assert (g["status"] == 0).all() and g["steps_per_thread"] == 20
+    mu = np.transpose(g["mu"], (0, 2, 1)); A = np.transpose(g["A"], (0, 3, 2, 1)); pe = np.transpose(g["pi_end"], (0, 2, 1))
+    assert (np.diff(mu, axis=2) > 0).all()
+    assert np.max(np.abs(A.sum(axis=3) - 1)) < 1e-12 and (A > 0).all()
+    assert np.max(np.abs(pe.sum(axis=2) - 1)) < 1e-12 and (g["sig2"] > 0).all() and np.isfinite(g["fcast"]).all()
+    assert np.max(np.abs(g["pif_final"].sum(axis=2) - 1)) < 1e-12
+    assert g["x_final"].min() >= 0 and g["x_final"].max() < K
+    rows = np.concatenate([g["mu"], g["sig2"], g["pi_end"], g["A"].reshape(W, K * K, n), g["fcast"]], axis=1)
+    assert np.max(np.abs((np.rint(rows * 1e5) / 1e5).mean(axis=2) - g["summary"])) < 1e-10
+    ids = np.array([0, 255, 256, 511])                      # first and second round of windows on the 256 CUs
+    sub = _lib.estimate_batch_host(np.ascontiguousarray(Y[ids]), Tw[ids], K, 3, n, (12,), yreal[ids], want_state=True, window_ids=ids)
+    for k in FLOAT_KEYS + ("x_final",):
+        assert np.array_equal(g[k][ids], sub[k]), k
+    o = oracle.estimate_window(Y[511], K, 3, n, (12,), yreal[511], window_id=511)
+    assert np.array_equal(g["x_final"][511], o["x_final"])
+    assert close(g["mu"][511].T, o["mu"]) < TOL and close(np.transpose(g["A"][511], (2, 1, 0)), o["A"]) < TOL
+    assert close(g["fcast"][511].T, o["fcast"]) < TOL and close(g["pif_final"][511], o["pif_final"]) < TOL
