@@ -93,6 +93,7 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr, copy = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;          // kernel timing
+    hipEvent_t ev_scr = nullptr;                      // device entry: last use of the shared scratch (scr, mom) on any stream
     hipEvent_t evk[RING] = {}, evc[RING] = {};        // chunk pipeline: kernel done / copy done
     int cu_count = 0;
     Arena dev, pin;
@@ -122,6 +123,7 @@ int get_context(int device, DeviceCtx** out)
         HIP_TRY(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&c.ev0));
         HIP_TRY(hipEventCreate(&c.ev1));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_scr, hipEventDisableTiming));
         for (int i = 0; i < RING; ++i) {
             HIP_TRY(hipEventCreateWithFlags(&c.evk[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.evc[i], hipEventDisableTiming));
@@ -145,6 +147,7 @@ void destroy_context(DeviceCtx& c)
     (void)hipStreamDestroy(c.copy);
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
+    (void)hipEventDestroy(c.ev_scr);
     for (int i = 0; i < RING; ++i) { (void)hipEventDestroy(c.evk[i]); (void)hipEventDestroy(c.evc[i]); }
     c.dev.release();
     c.pin.release();
@@ -394,6 +397,10 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
     p.nd_ld = p.nd; p.draw_off = 0;
 
     if (!resume) HIP_TRY(hipMemsetAsync(dstatus, 0, sizeof(int32_t) * (size_t)cfg->W, stream));
+    // The pdf scratch and the moment tables belong to the device context, not to the call: an enqueue-only call on another
+    // stream may still be using them, so this launch is ordered behind their last use.
+    const bool uses_scratch = pl.bv != nullptr || (ex && ex->corr);
+    if (uses_scratch) HIP_TRY(hipStreamWaitEvent(stream, c.ev_scr, 0));
     if (pl.bv) {
         HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
         const size_t sbytes = pl.scratch_bytes(cfg->W, cfg->K);
@@ -420,6 +427,7 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
         HIP_TRY(hmcg_host::launch_moments(ma, stream));
         HIP_TRY(hmcg_host::launch_corr_finalize(reinterpret_cast<double*>(c.mom.base), ex->corr, cfg->W, cfg->K, stream));
     }
+    if (uses_scratch) HIP_TRY(hipEventRecord(c.ev_scr, stream));
 #ifdef HMCG_STAMPS
     rc = print_stamps(p, pl, ddbg, ndbg, stream);
     (void)hipFree(ddbg);

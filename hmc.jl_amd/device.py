@@ -15,7 +15,7 @@ class DevicePanel:
     (include/hmcg.h): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun), fcast (W,2H,nrun),
     summary (W, 3K+K^2+2H), status (W,)."""
 
-    def __init__(self, Y, T, K, nrun, horizons=(12,), yreal=None, device=0, window_ids=None, keep_draws=True):
+    def __init__(self, Y, T, K, nrun, horizons=(12,), yreal=None, device=0, window_ids=None, keep_draws=True, corr=False):
         import torch
         if not torch.cuda.is_available():
             raise _lib.HmcgError("no GPU visible to torch: hmc.jl_amd has no CPU fallback")
@@ -45,6 +45,9 @@ class DevicePanel:
             self.mu = self.sig2 = self.A = self.pi_end = self.fcast = None
         self.summary = torch.zeros((W, self.NS), **f64)
         self.status = torch.zeros(W, dtype=torch.int32, device=self.dev)
+        # extras.corr: (W, NC, NC) correlations between the per-draw outputs (calccorr), needs the draws on the device
+        NC = 3 * K + K * K + 1
+        self.corr = torch.zeros((W, NC, NC), **f64) if corr else None
         self.last_timing = None
         torch.cuda.synchronize(self.dev)   # fills above ran on torch's stream; the library uses its own
 
@@ -58,10 +61,13 @@ class DevicePanel:
         cfg = _lib.make_config(self.W, self.K, self.ldY, self.max_T, burnin, self.nrun, self.horizons, seed,
                                window_base, self.device_index, 0, threads_per_window)
         ex = None
-        if self.window_ids is not None:
+        if self.window_ids is not None or self.corr is not None:
             ex = _lib.Extras()
             ex.struct_size = C.sizeof(_lib.Extras)
-            ex.window_ids = self.window_ids.data_ptr()
+            if self.window_ids is not None:
+                ex.window_ids = self.window_ids.data_ptr()
+            if self.corr is not None:
+                ex.corr = self.corr.data_ptr()
         tm = _lib.estimate_batch_device(cfg, self.Y.data_ptr(), self.T.data_ptr(), self._ptr(self.yreal),
                                         self._ptr(self.mu), self._ptr(self.sig2), self._ptr(self.A),
                                         self._ptr(self.pi_end), self._ptr(self.fcast), self.summary.data_ptr(),

@@ -100,3 +100,23 @@ def test_calccorr_device_matrices_equal_the_file_route(inflation, tmp_path):
     # without the draws: same matrices, nothing but summaries and correlations crosses PCIe
     lean = hmc.estimatewindows(y, dd, ends, horizons=[12], D=3, burnin=300, Nrun=3000, series="official", keep_draws=False, corr=True)
     assert np.array_equal(lean.corr, res.corr, equal_nan=True)
+
+
+def test_corr_device_entry_equals_host_entry():
+    """hmcg_estimate_batch_device with extras.corr (device pointers, one launch) against the chunked host entry: the same
+    bits -- the moments are accumulated in draw order whatever the chunking.  K = 8 runs the LDS-resident kernel, whose pdf
+    scratch shares the device context with the moment tables."""
+    from hmc_jl_amd import _lib, synth
+    from hmc_jl_amd.device import DevicePanel
+    for K, T, nrun in ((3, 500, 800), (8, 700, 200)):
+        W = 6
+        Y, Tw, fut = synth.generate_panel(W, T, K)
+        host = _lib.estimate_batch_host(Y, Tw, K, 20, nrun, (12,), fut[:, 11:12], want_corr=True)
+        p = DevicePanel(Y, Tw, K, nrun, (12,), fut[:, 11:12], corr=True)
+        p.run(burnin=20)
+        p.run(burnin=20, timed=False)          # enqueue-only second run on the same context: ordered behind the first
+        p.sync()
+        assert np.array_equal(p.corr.cpu().numpy(), host["corr"], equal_nan=True)
+        assert np.array_equal(p.mu.cpu().numpy(), host["mu"])
+    with pytest.raises(_lib.HmcgError):        # the device entry cannot make up the draw arrays
+        DevicePanel(Y, Tw, K, nrun, (12,), fut[:, 11:12], corr=True, keep_draws=False).run(burnin=20)
