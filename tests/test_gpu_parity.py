@@ -216,10 +216,16 @@ def test_filtered_probability_mean_and_reference_insample_fixture(hmclib, oracle
     assert np.array_equal(only["pi_filter_mean"], g["pi_filter_mean"]) and np.array_equal(only["mu"], g["mu"])
     rows = list(csv.DictReader(open(os.path.join(os.path.dirname(__file__), "golden", "official_insample_forecats_insample.csv"))))
     s = np.array([[float(r["s1"]), float(r["s2"]), float(r["s3"])] for r in rows])
-    big = _lib.estimate_batch_host(Y, Tw, 3, 20000, 10000, (12,), np.array([[y[587]]]), want_draws=False, want_filter_mean=True)
+    big = _lib.estimate_batch_host(Y, Tw, 3, 20000, 10000, (12,), np.array([[y[587]]]), want_filter_mean=True)
     d = np.abs(big["pi_filter_mean"][0] - s)
     assert d.mean() < 0.02 and d.max() < 0.3
     assert min(np.corrcoef(big["pi_filter_mean"][0][:, k], s[:, k])[0, 1] for k in range(3)) > 0.99
+    # (3) the fixture's `forecast` column, to first order (see the oracle test): mean_j pif_j[t,:] . mean_j A_j^12 mu_j
+    fc = np.array([float(r["forecast"]) for r in rows])
+    A12 = np.linalg.matrix_power(np.transpose(big["A"][0], (2, 1, 0)), 12)
+    c = np.einsum("nij,nj->ni", A12, big["mu"][0].T).mean(axis=0)
+    f1 = big["pi_filter_mean"][0] @ c
+    assert np.abs(f1 - fc).mean() < 0.07 and np.abs(f1 - fc).max() < 0.7 and np.corrcoef(f1, fc)[0, 1] > 0.997
 
 
 def test_mixed_lengths_in_one_call(hmclib, oracle):
