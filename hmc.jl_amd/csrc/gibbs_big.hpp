@@ -813,7 +813,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                             if (p.pi_filter_mean) p.pi_filter_mean[((size_t)w * p.ldY + t) * K + q] += fq;         // sorted pif[t,:] (:512)
                         }
                         double fv[K], fb[K], nb[K];
-                        pdfs(th, ylds[t], true, fv);
+#pragma unroll
+                        for (int s = 0; s < K; ++s) fv[s] = fscr[((size_t)l * K + s) * NT];    // this step's pdfs, from the product phase
 #pragma unroll
                         for (int s = 0; s < K; ++s) fb[s] = fv[s] * b[s];
 #pragma unroll
