@@ -540,11 +540,26 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 th.At[e % K][i] = a;
             }
         } else {
-            const int nblk = (T + 1) >> 1;
             if (sweep > p.sweep_begin) job_outputs(sweep - 1);
             if (shadow_wave == NSH - 1 && sweep + 1 < p.sweep_end) job_prep(sweep + 1);
-            const int per = (nblk + NSH - 1) / NSH;
-            job_uniforms(sweep, shadow_wave * per, min((shadow_wave + 1) * per, nblk));
+        }
+        {
+            // This sweep's (T+1)/2 Philox blocks of state-draw uniforms, dealt in proportion to what else a wave carries in
+            // this phase (stamps at K=8, T=5000: parameter draw 4.8 k ticks, parameter outputs 3.4 k, forecast + next
+            // sweep's RNG preparation 8.5 k, a third of the uniforms 7.7 k): 4/16 to the parameter wave, 4/16 to the output
+            // wave, 7/16 to the wave with no fixed job, the rest to the forecast wave; further waves share evenly.
+            const int nblk = (T + 1) >> 1;
+            int b0, b1;
+            if constexpr (NW == 4) {
+                const int c0 = (nblk * 4) / 16, c1 = (nblk * 8) / 16, c2 = (nblk * 15) / 16;
+                const int wu = __builtin_amdgcn_readfirstlane(wave);
+                b0 = wu == 0 ? 0 : (wu == 1 ? c0 : (wu == 2 ? c1 : c2));
+                b1 = wu == 0 ? c0 : (wu == 1 ? c1 : (wu == 2 ? c2 : nblk));
+            } else {
+                const int per = (nblk + NW - 1) / NW;
+                b0 = wave * per; b1 = min((wave + 1) * per, nblk);
+            }
+            job_uniforms(sweep, b0, b1);
         }
         STAMP(1);
         __syncthreads();                                                     // Bb
