@@ -871,9 +871,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         // words, where (a o b) is two v_perm_b32 -- the selector bytes 0..7 of b pick from the eight bytes {a.hi, a.lo} --
         // instead of eight shift-mask-shift-or rounds.
         ByteMap G = bytemap_identity();
-        for (int l = L - 1; l >= 0; --l) {
+        uint32_t mnext = maps[t0 + L - 1];           // (the next step's map is fetched one iteration ahead: the loop is a
+        for (int l = L - 1; l >= 0; --l) {           //  dependent chain of v_perm's, the LDS latency must not be on it)
             const int t = t0 + l;
-            uint32_t m = maps[t];
+            uint32_t m = mnext;
+            if (l > 0) mnext = maps[t - 1];
             m = (t == T - 1) ? map_const<K>(xlast) : (t > T - 1 ? map_identity<K>() : m);
             maps[t] = m;
             G = bytemap_compose(bytemap_from_nibbles(m), G);
@@ -908,9 +910,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         Hx.hi = __shfl_down(Hm.hi, 1, 64);
         if (lane == 63) Hx = bytemap_identity();
         int sin = (int)(bytemap_compose(Hx, Rw).lo & 0xFFu);               // entry 0 (a constant map below T-1)
+        uint32_t anext = maps[t0 + L - 1];
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
-            if (t < T) { sin = map_apply(maps[t], sin); xs[t] = (uint8_t)sin; }
+            const uint32_t am = anext;
+            if (l > 0) anext = maps[t - 1];
+            if (t < T) { sin = map_apply(am, sin); xs[t] = (uint8_t)sin; }
         }
         x_end = xlast;
         if (tid < K) sh.pivot[tid] = th.mu[tid];                             // pivots of the next one-pass statistics
