@@ -370,19 +370,27 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         double d1[K], d2[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) { d1[i] = 0.0; d2[i] = 0.0; }
+        // (software-pipelined: the state two steps ahead, the observation and the pivot one step ahead are in flight while
+        //  a step is accumulated -- as a plain loop every iteration waited for two dependent LDS reads, x then pivot[x])
+        int xc = min((int)xs[t0], K - 1), xn = min((int)xs[t0 + 1], K - 1);
+        double yc = ylds[t0], pc = sh.pivot[xc];
         for (int l = 0; l < L; ++l) {
             const int t = t0 + l;
+            const int xnn = min((int)xs[t + 2], K - 1);                  // xs has 8 spare entries behind cap
+            const double yn = ylds[min(t + 1, cap - 1)];
+            const double pn = sh.pivot[xn];
             if (t < T) {
-                const int xv = xs[t];
-                const double dl = ylds[t] - sh.pivot[xv];
+                const int xv = xc;
+                const double dl = yc - pc;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     const double dm = (xv == i) ? dl : 0.0;
                     d1[i] += dm;
                     d2[i] = fma(dm, dm, d2[i]);
                 }
-                if (t + 1 < T) atomicAdd(&sh.cnt[wave][xv * K + xs[t + 1]], 1u);
+                if (t + 1 < T) atomicAdd(&sh.cnt[wave][xv * K + xn], 1u);
             }
+            xc = xn; xn = xnn; yc = yn; pc = pn;
         }
         double o0, o1, v8[8];
 #pragma unroll
