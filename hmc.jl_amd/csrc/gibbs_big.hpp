@@ -5,14 +5,17 @@
 //     sweep's uniforms and the per-step state maps live in (dynamic) LDS, and the loops over a
 //     thread's L = ceil(T/256) consecutive steps are runtime loops;
 //   * the transition matrix is read from LDS, one column at a time (stored transposed so a column is
-//     contiguous), and the pdfs are recomputed in the replay instead of being kept;
+//     contiguous); a step's K pdfs are evaluated once, in the product phase, and reach the replay (and the smoothing
+//     pass) through a lane-contiguous HBM scratch, KernelParams::fscr;
 //   * the state map g_{t-1} is built inside the filter replay at step t: the running sums
 //     sum_{r' <= r} pif[t-1,r'] A[r',s] that give pif[t,s] are exactly the cumulative weights of the
 //     draw X[t-1] | X[t] = s (src/Hmc.jl:468-481), and the eps() guard pif[t,s] is at hand -- so
 //     the filtered probabilities never have to be stored (pif is neither kept in registers nor
 //     written to HBM; only pif[T-1,:] leaves the replay);
 //   * transition counts go through per-wave LDS histograms (integer atomics: order-independent),
-//     parameter-draw roles (K + K^2 = 72 at K = 8) and output roles take more than one pass over a wave.
+//     parameter-draw roles (K + K^2 = 72 at K = 8) and output roles take more than one pass over a wave;
+//   * the state maps are 4-bit per entry in LDS and widened to a byte per entry (two words, composed by two
+//     v_perm_b32) for the backward pass; runtime loops whose iterations start with an LDS read are pipelined by hand.
 // Reference lines: as in gibbs_device.hpp.
 #pragma once
 #include "gibbs_device.hpp"
