@@ -623,20 +623,46 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
             rescale_pow2<KK>(Q);
         } else {
-            int l = 0;
-            for (; l + 1 < L; l += 2) {
-                mstep(Q, N, l);
-                mstep(N, Q, l + 1);
+            // In place, four rows at a time: row r of Q (A diag f) needs row r of Q only, so once a block of rows has all
+            // its columns it replaces the block it came from -- one matrix and half a matrix live (192 registers) instead of
+            // two (256, i.e. ~190 VGPR<->AGPR copies per step); the price is that every column of A is read once per block
+            // (twice per step for K = 8: 64 broadcast reads instead of 32, far from loading the LDS pipe -- the two-rows
+            // form that read A four times per step had been LDS-bound).
+            constexpr int RB = 4;
+            for (int l = 0; l < L; ++l) {
+                asm volatile("" ::: "memory");
+                double fv[K];
+                pdfs(th, ylds[t0 + l], t0 + l < T, fv);
+#pragma unroll
+                for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
+#pragma unroll
+                for (int r0 = 0; r0 < K; r0 += RB) {
+                    double tb[RB][K];
+#pragma unroll
+                    for (int s = 0; s < K; ++s) {
+                        double a[K];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
+#pragma unroll
+                        for (int rr = 0; rr < RB; ++rr) {
+                            if (r0 + rr < K) {
+                                double acc = Q[(r0 + rr) * K] * a[0];
+#pragma unroll
+                                for (int k = 1; k < K; ++k) acc = fma(Q[(r0 + rr) * K + k], a[k], acc);
+                                tb[rr][s] = acc * fv[s];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+                        for (int s = 0; s < K; ++s) if (r0 + rr < K) Q[(r0 + rr) * K + s] = tb[rr][s];
+                }
                 // (every step's largest pdf lies in [0.5,1): four steps between two exact power-of-two rescalings are far
                 //  inside the fp64 range)
-                if (l & 2) rescale_pow2<KK>(Q);
+                if ((l & 3) == 3) rescale_pow2<KK>(Q);
             }
-            if (l < L) {
-                mstep(Q, N, l);
-#pragma unroll
-                for (int i = 0; i < KK; ++i) Q[i] = N[i];
-                rescale_pow2<KK>(Q);
-            }
+            rescale_pow2<KK>(Q);
         }
         double Qloc[SM ? KK : 1];                                 // this thread's own chunk product, for the suffix scan
         if constexpr (SM) {
