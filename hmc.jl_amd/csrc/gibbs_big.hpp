@@ -582,57 +582,29 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
             for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
         double N[KK];
-        // Q <- Q * (A diag(f_t)): one column of A at a time from LDS (wave-uniform address: a broadcast read), all K rows
-        // against it -- K independent accumulation chains.  (An in-place, two-rows-at-a-time form that keeps a single
-        // matrix live was measured: it frees the AGPR copies but reads A four times as often and lost 9 % to the LDS pipe.)
-        auto mstep = [&](const double (&in)[KK], double (&out)[KK], int l) __attribute__((always_inline)) {
-            asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
-            double fv[K];
-            pdfs(th, ylds[t0 + l], t0 + l < T, fv);
-            // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
-            // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
-#pragma unroll
-            for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                double a[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
-#pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    double acc = in[r * K] * a[0];
-#pragma unroll
-                    for (int k = 1; k < K; ++k) acc = fma(in[r * K + k], a[k], acc);
-                    out[r * K + s] = acc * fv[s];
-                }
-            }
-        };
         const bool kept_sweep = sweep >= p.burnin_s;              // one sample per launch on this path
         const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr);
-        if constexpr (SM) {
-            for (int l = 0; l < L; ++l) {
-                if (t0 + l < T) {                                 // padded steps stay out of the products (identity)
-                    mstep(Q, N, l);
-#pragma unroll
-                    for (int i = 0; i < KK; ++i) Q[i] = N[i];
-                    if (l & 1) rescale_pow2<KK>(Q);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = 1.0;
-                }
-            }
-            rescale_pow2<KK>(Q);
-        } else {
-            // In place, four rows at a time: row r of Q (A diag f) needs row r of Q only, so once a block of rows has all
-            // its columns it replaces the block it came from -- one matrix and half a matrix live (192 registers) instead of
-            // two (256, i.e. ~190 VGPR<->AGPR copies per step); the price is that every column of A is read once per block
-            // (twice per step for K = 8: 64 broadcast reads instead of 32, far from loading the LDS pipe -- the two-rows
-            // form that read A four times per step had been LDS-bound).
+        {
+            // Q <- Q * (A diag(f_t)), in place, four rows at a time: row r of the product needs row r of Q only, so once a
+            // block of rows has all its columns it replaces the block it came from -- one matrix and half a matrix live
+            // (192 registers) instead of two (256, i.e. ~190 VGPR<->AGPR copies per step).  One column of A at a time from
+            // LDS (wave-uniform address: a broadcast read), the block's rows against it; every column is read once per block
+            // (twice per step for K = 8: 64 broadcast reads instead of 32, far from loading the LDS pipe -- a two-rows form
+            // that read A four times per step had been LDS-bound).
             constexpr int RB = 4;
             for (int l = 0; l < L; ++l) {
-                asm volatile("" ::: "memory");
+                asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
+                if constexpr (SM) {
+                    if (t0 + l >= T) {               // padded steps stay out of the products (identity): the suffix scan
+#pragma unroll                                       //  of the smoothing pass must not see them
+                        for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = 1.0;
+                        continue;
+                    }
+                }
                 double fv[K];
                 pdfs(th, ylds[t0 + l], t0 + l < T, fv);
+                // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
+                // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
 #pragma unroll
                 for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
 #pragma unroll
