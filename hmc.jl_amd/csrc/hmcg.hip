@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -87,6 +89,66 @@ struct Layout {
 
 constexpr int RING = 3;            // chunk buffers in flight (device and pinned)
 
+// A few persistent host threads that share the scatter of a chunk (pinned staging -> the caller's arrays: 41 MB per call
+// at the headline shape, as many small memcpys) with the calling thread.  On hosts whose single-thread copy rate is below
+// the device's draw rate the scatter, not the GPU, would otherwise set the pace of the host entry.
+class ScatterPool {
+public:
+    ~ScatterPool() { if (!th_.empty()) stop(); }
+    void start(int workers)
+    {
+        if (!th_.empty() || workers <= 0) return;
+        for (int i = 0; i < workers; ++i) th_.emplace_back([this, i] { loop(i); });
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m_); quit_ = true; ++gen_; }
+        go_.notify_all();
+        for (auto& t : th_) t.join();
+        th_.clear();
+        quit_ = false;
+    }
+    // f(part, nparts) for part = 0..nparts-1, nparts = workers + 1; returns when every part is done
+    void run(const std::function<void(int, int)>& f)
+    {
+        const int np = (int)th_.size() + 1;
+        if (np == 1) { f(0, 1); return; }
+        { std::lock_guard<std::mutex> lk(m_); job_ = &f; pending_ = np - 1; ++gen_; }
+        go_.notify_all();
+        f(np - 1, np);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    void loop(int id)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* f;
+            int np;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                go_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (quit_) return;
+                f = job_;
+                np = (int)th_.size() + 1;
+            }
+            if (f) (*f)(id, np);
+            { std::lock_guard<std::mutex> lk(m_); --pending_; }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable go_, done_;
+    const std::function<void(int, int)>* job_ = nullptr;
+    unsigned long gen_ = 0;
+    int pending_ = 0;
+    bool quit_ = false;
+};
+
 struct DeviceCtx {
     std::mutex mu;                 // serialises calls on this device
     bool ready = false;
@@ -99,6 +161,7 @@ struct DeviceCtx {
     Arena dev, pin;
     Arena mom;                     // device entry: the draw-moment tables behind extras.corr
     Arena scr;                     // device entry: the LDS-resident kernel's pdf scratch
+    ScatterPool pool;              // host entries: helpers for the scatter into the caller's arrays
 };
 DeviceCtx g_ctx[HMCG_MAXDEV];
 std::mutex g_init_mu;
@@ -130,6 +193,14 @@ int get_context(int device, DeviceCtx** out)
         }
         HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, device));
         c.pin.pinned = true;
+        {
+            // HMCG_SCATTER_THREADS: helper threads per device for the host-side scatter (default 3, 0 = the caller alone)
+            int nw = 3;
+            if (const char* e = getenv("HMCG_SCATTER_THREADS")) nw = atoi(e);
+            const int hc = (int)std::thread::hardware_concurrency();
+            if (hc > 0) nw = std::min(nw, std::max(0, hc - 1));
+            c.pool.start(std::max(0, std::min(nw, 16)));
+        }
         c.device = device;
         c.ready = true;
     }
@@ -153,6 +224,7 @@ void destroy_context(DeviceCtx& c)
     c.pin.release();
     c.mom.release();
     c.scr.release();
+    c.pool.stop();
     c.stream = c.copy = nullptr;
     c.ready = false;
     c.device = -1;
@@ -673,15 +745,21 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         const Chunk& ch = chunks[cidx];
         const size_t ndc = (size_t)(ch.d1 - ch.d0);
         const double* src = PP(double, o_pchunk[cidx % RING]);
-        for (int i = 0; i < n; ++i) {
-            const size_t g = row(i);
-            for (const Col& cc : cols) {
-                if (!cc.host) continue;
-                for (size_t q = 0; q < cc.ncol; ++q)
-                    memcpy(cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0,
-                           src + ndc * (cc.off * N + q + cc.ncol * (size_t)i), 8 * ndc);
+        if (!copy_out || ndc == 0) return;
+        const std::function<void(int, int)> part = [&](int pi, int np) {          // windows [i0, i1) of this chunk
+            const int i0 = (int)((long long)n * pi / np), i1 = (int)((long long)n * (pi + 1) / np);
+            for (int i = i0; i < i1; ++i) {
+                const size_t g = row(i);
+                for (const Col& cc : cols) {
+                    if (!cc.host) continue;
+                    for (size_t q = 0; q < cc.ncol; ++q)
+                        memcpy(cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0,
+                               src + ndc * (cc.off * N + q + cc.ncol * (size_t)i), 8 * ndc);
+                }
             }
-        }
+        };
+        if (8 * ncols * N * ndc < ((size_t)1 << 20)) part(0, 1);                  // small chunks: not worth a hand-off
+        else c.pool.run(part);
     };
     int next_scatter = 0;
     for (int cidx = 0; cidx < nch; ++cidx) {
