@@ -532,15 +532,18 @@ long long sweep_after_kept(long long d, int per, int burnin, int nrun)
 
 struct Chunk { int s0, s1; long long d0, d1; };   // sweeps [s0, s1) produce the kept draws [d0, d1)
 
-// Chunks of the sweep range [sb, se): draw counts halve from chunk to chunk down to ~1/16 of the run (the last chunk's
-// copy-out is the only one not hidden behind sampling), never more than `cap` draws in a chunk.
+// Chunks of the sweep range [sb, se): draw counts halve from chunk to chunk down to ~1/32 of the run (the last chunk's
+// copy-out is the only one not hidden behind sampling; HMCG_CHUNK_FLOOR_DIV overrides the 32), never more than `cap`
+// draws in a chunk.
 std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int nrun, long long cap, bool stream_draws)
 {
     std::vector<Chunk> out;
     const long long dB = kept_before(sb, per, burnin, nrun), dE = kept_before(se, per, burnin, nrun);
     const long long nd = dE - dB;
     if (!stream_draws || nd <= 0 || se <= sb) { out.push_back({sb, se, dB, dE}); return out; }
-    const long long floor_sz = std::max(16LL, nd / 16);
+    long long fdiv = 32;       // (measured at the headline shape: 1/8 5.34 ms, 1/16 5.30, 1/32 5.23 per call)
+    if (const char* e = getenv("HMCG_CHUNK_FLOOR_DIV")) { const long long v = atoll(e); if (v >= 2 && v <= 1024) fdiv = v; }
+    const long long floor_sz = std::max(16LL, nd / fdiv);
     long long d = dB;
     int s = sb;
     while (d < dE) {
