@@ -738,7 +738,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 }
                 const double inv = rcp_fast(total);
                 int idx_uni = 0;
-                {
+                if constexpr ((K & (K - 1)) == 0) {
+                    idx_uni = (int)(u * (double)K);         // K a power of two: the cumulative j/K are exact, #{j/K <= u} = floor(K u), u < 1
+                } else {
                     double cp = 0.0;
 #pragma unroll
                     for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx_uni += (cp <= u) ? 1 : 0; }
