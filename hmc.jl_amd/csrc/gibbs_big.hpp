@@ -91,6 +91,30 @@ __device__ __forceinline__ int count_le_sorted(const double (&c)[N + 1], double 
     return (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);
 }
 
+// The same for K searches at once, level by level: idx[s] = #{i < K-1 : c[s][i] <= thr[s]}.  Written so that the K
+// compares of a level are independent instructions (each into its own condition register) instead of K serial
+// compare -> select chains through VCC.
+template <int K>
+__device__ __forceinline__ void count_le_sorted_batch(const double (&c)[K][K], const double (&thr)[K], int (&idx)[K])
+{
+    constexpr int N = K - 1;
+    static_assert(N >= 1 && N <= 7, "three levels");
+    constexpr double INF = __builtin_huge_val();
+    auto C = [&](int s, int i) __attribute__((always_inline)) { return i < N ? c[s][i < N ? i : 0] : INF; };
+    bool b1[K], b2[K];
+    double m2[K], lo3[K], hi3[K], m3[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) b1[s] = C(s, 3) <= thr[s];
+#pragma unroll
+    for (int s = 0; s < K; ++s) { m2[s] = b1[s] ? C(s, 5) : C(s, 1); lo3[s] = b1[s] ? C(s, 4) : C(s, 0); hi3[s] = b1[s] ? C(s, 6) : C(s, 2); }
+#pragma unroll
+    for (int s = 0; s < K; ++s) b2[s] = m2[s] <= thr[s];
+#pragma unroll
+    for (int s = 0; s < K; ++s) m3[s] = b2[s] ? hi3[s] : lo3[s];
+#pragma unroll
+    for (int s = 0; s < K; ++s) idx[s] = (b1[s] ? 4 : 0) + (b2[s] ? 2 : 0) + ((m3[s] <= thr[s]) ? 1 : 0);
+}
+
 template <int K, int NT, bool SM = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
@@ -713,20 +737,27 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 }
                 double nv[K], total = 0.0;
                 uint32_t mok = 0;
+                {
+                    // the K cumulative-sum chains first, then the K categorical draws level by level (count_le_sorted_batch):
+                    // one search after another is a chain of compare -> select -> compare through VCC, K of them in a row
+                    double cum[K][K], thr[K];
 #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    double a[K], cum[K];
+                    for (int s = 0; s < K; ++s) {
+                        double a[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
-                    double acc = av[0] * a[0];
-                    cum[0] = acc;
+                        for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
+                        double acc = av[0] * a[0];
+                        cum[s][0] = acc;
 #pragma unroll
-                    for (int r = 1; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[r] = acc; }
-                    const double thr = u * acc;
-                    const int idx = count_le_sorted<K - 1>(cum, thr);
-                    mok |= (uint32_t)idx << (4 * s);
-                    nv[s] = acc * fv[s];
-                    total += nv[s];
+                        for (int r = 1; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[s][r] = acc; }
+                        thr[s] = u * acc;
+                        nv[s] = acc * fv[s];
+                        total += nv[s];
+                    }
+                    int idx[K];
+                    count_le_sorted_batch<K>(cum, thr, idx);
+#pragma unroll
+                    for (int s = 0; s < K; ++s) mok |= (uint32_t)idx[s] << (4 * s);
                 }
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(total > 0.0)) != 0ull, 0)) {
                     if (!(total > 0.0)) {
