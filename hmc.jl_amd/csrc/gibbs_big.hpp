@@ -724,8 +724,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             double fnext[K];                     // pdfs of the step ahead, on their way from the scratch
 #pragma unroll
             for (int s = 0; s < K; ++s) fnext[s] = fscr[(size_t)s * NT];
+            constexpr int NRES = 2;              // the first columns of A stay in registers: the step's first chains need not wait for LDS
+            double a_first[NRES][K];
+#pragma unroll
+            for (int s = 0; s < NRES; ++s)
+#pragma unroll
+                for (int k = 0; k < K; ++k) a_first[s][k] = Atp[s * K + k];
             for (int l = 0; l < L; ++l) {
-                asm volatile("" ::: "memory");       // as above: A stays in LDS
+                asm volatile("" ::: "memory");       // as above: (the rest of) A stays in LDS
                 const int t = t0 + l;
                 const double u = uxs[t >= 1 ? t - 1 : 0];
                 double fv[K];
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     for (int s = 0; s < K; ++s) {
                         double a[K];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
+                        for (int k = 0; k < K; ++k) a[k] = s < NRES ? a_first[s < NRES ? s : 0][k] : Atp[s * K + k];
                         double acc = av[0] * a[0];
                         cum[s][0] = acc;
 #pragma unroll
