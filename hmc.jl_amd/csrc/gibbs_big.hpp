@@ -654,9 +654,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                         for (int s = 0; s < K; ++s) if (r0 + rr < K) Q[(r0 + rr) * K + s] = tb[rr][s];
                 }
-                // (every step's largest pdf lies in [0.5,1): four steps between two exact power-of-two rescalings are far
+                // (every step's largest pdf lies in [0.5,1): eight steps between two exact power-of-two rescalings are far
                 //  inside the fp64 range)
-                if ((l & 3) == 3) rescale_pow2<KK>(Q);
+                if ((l & 7) == 7) rescale_pow2<KK>(Q);
             }
             rescale_pow2<KK>(Q);
         }
