@@ -1,0 +1,71 @@
+"""Seeded random shapes through the host entry against the oracle: states bit-exact, floats within 1e-9 -- a net under the
+per-variant tests for what no hand-picked case hits (window lengths around the chunk and wave boundaries of every kernel,
+odd horizon sets, short chains, explicit RNG stream ids, forced flavours, chunked launches)."""
+import os
+
+import numpy as np
+import pytest
+
+from hmc_jl_amd import synth
+from test_gpu_parity import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    K = int(rng.integers(2, 9))
+    W = int(rng.integers(1, 5))
+    # lengths: mostly near a boundary of the kernel ladder (256 threads x 1, 2, 4, 8, 16 steps; the LDS kernel beyond)
+    top = 2300 if K <= 4 else 1400
+    anchors = [2, 3, 64, 65, 256, 257, 512, 513, 1024, 1025, 2048, 2049]
+    lens = []
+    for _ in range(W):
+        if rng.random() < 0.6:
+            a = int(rng.choice([x for x in anchors if x <= top]))
+            lens.append(int(np.clip(a + rng.integers(-3, 4), 2, top)))
+        else:
+            lens.append(int(rng.integers(2, top + 1)))
+    H = int(rng.integers(0, 3))
+    horizons = tuple(int(h) for h in rng.choice(np.arange(1, 41), size=H, replace=False))
+    return K, lens, horizons, int(rng.integers(0, 4)), int(rng.integers(1, 7))
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_shapes_against_oracle(hmclib, oracle, seed, monkeypatch):
+    rng = np.random.default_rng(1000 + seed)
+    K, lens, horizons, burnin, nrun = _case(rng)
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, horizon_pad=41, ragged=lens, window_base=seed * 7)
+    yreal = np.stack([fut[:, h - 1] for h in horizons], axis=1) if horizons else None
+    wids = None
+    if seed % 3 == 0:
+        wids = rng.integers(0, 2**31, size=len(lens)).astype(np.int64)
+    if seed % 4 == 1 and K <= 4:
+        monkeypatch.setenv("HMCG_FLAVOUR", ["p1", "p2", "h"][seed % 3])
+    if seed % 5 == 2:
+        monkeypatch.setenv("HMCG_CHUNK_DRAWS", "2")
+    g = check_against_oracle(oracle, Y, Tw, K, burnin, nrun, horizons, yreal, window_ids=wids, seed=4321 + seed)
+    assert (g["status"] == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_signal_runs_against_oracle(hmclib, oracle, seed):
+    """The same for the signal Monte-Carlo path (estimatesignals!, sigLen = 0): random signal tails, save ranges, noise
+    levels, kappa and numbers of chained noise samples, K = 2..4 across the steps-per-thread variants."""
+    from test_gpu_parity import check_signals_against_oracle
+    rng = np.random.default_rng(5000 + seed)
+    K = int(rng.integers(2, 5))
+    W = int(rng.integers(1, 4))
+    top = [1000, 2040, 1000][K - 2]                      # signal variants: K=2 L<=4, K=3 L<=8, K=4 L<=4
+    lens = [int(rng.integers(8, top + 1)) for _ in range(W)]
+    Y, Tw, fut = synth.generate_panel(W, max(lens), K, ragged=lens, window_base=seed)
+    sig = np.zeros((W, 2), dtype=np.int32)
+    save = np.zeros((W, 2), dtype=np.int32)
+    for w, T in enumerate(lens):
+        slen = int(rng.integers(1, T + 1)) if rng.random() < 0.7 else T          # a tail, or everything a signal
+        sig[w] = (T - slen, T)
+        ns = int(rng.integers(1, min(slen, 6) + 1))
+        save[w] = (T - ns, T)
+    ssig = rng.uniform(0.0, 2.0, size=W)
+    kappa = float(rng.choice([0.1, 0.3, 0.6, 1.0]))
+    check_signals_against_oracle(oracle, Y, Tw, K, int(rng.integers(0, 4)), int(rng.integers(1, 6)), int(rng.integers(1, 4)),
+                                 sig, save, kappa, 2.0, 2.0, ssig, fut[:, 11:12])
