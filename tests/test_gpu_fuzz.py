@@ -70,3 +70,27 @@ def test_random_signal_runs_against_oracle(hmclib, oracle, seed):
     kappa = float(rng.choice([0.1, 0.3, 0.6, 1.0]))
     check_signals_against_oracle(oracle, Y, Tw, K, int(rng.integers(0, 4)), int(rng.integers(1, 6)), int(rng.integers(1, 4)),
                                  sig, save, kappa, 2.0, 2.0, ssig, fut[:, 11:12])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HMCG_FUZZ_N", "96")) // 4))
+def test_random_smoothing_runs_against_oracle(hmclib, oracle, seed):
+    """extras.pi_smooth_mean / pi_filter_mean on random shapes, K = 2..8: the SMOOTH variants of the register-resident
+    kernel, the smoothing variant of the LDS-resident one beyond their range, against the oracle's literal Pb recursion."""
+    from hmc_jl_amd import _lib
+    from test_gpu_parity import TOL, close
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.integers(2, 9))
+    W = int(rng.integers(1, 4))
+    top = 2300 if K <= 4 else 900
+    lens = [int(rng.integers(2, top + 1)) for _ in range(W)]
+    Y, Tw, fut = synth.generate_panel(W, max(lens), K, ragged=lens, window_base=seed)
+    burnin, nrun = int(rng.integers(0, 3)), int(rng.integers(1, 5))
+    g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
+    for w in range(W):
+        T = int(Tw[w])
+        o = oracle.estimate_window(Y[w, :T], K, burnin, nrun, (12,), fut[w, 11:12], window_id=w, want_smooth=True)
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :T], o["x_final"])
+        assert np.max(np.abs(g["pi_smooth_mean"][w, :T] - o["pi_smooth"].mean(axis=0))) < TOL
+        assert np.max(np.abs(g["pi_filter_mean"][w, :T].sum(axis=1) - 1)) < 1e-12
+        assert close(g["mu"][w].T, o["mu"]) < TOL and close(g["pif_final"][w, :T], o["pif_final"]) < TOL
