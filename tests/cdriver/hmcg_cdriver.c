@@ -6,6 +6,7 @@
  *   mode 2  hmcg_estimate_batch_multi               (windows partitioned over the listed devices)
  *   mode 3  timing loop over hmcg_estimate_batch with caller-owned, reused buffers (what a Julia caller does):
  *           prints the mean wall time per call; bench.py reports it as the end-to-end figure of the C ABI
+ *   mode 4  hmcg_estimate_batch with extras.corr    (calccorr's matrices, src/Hmc.jl:1094-1163, taken on the device)
  * and writes the raw outputs for the pytest wrapper to compare with the oracle.
  * usage: hmcg_cdriver <request.bin> <response.bin> */
 #include <stdint.h>
@@ -58,6 +59,9 @@ int main(int argc, char** argv)
     memset(&ex, 0, sizeof ex);
     ex.struct_size = (int32_t)sizeof ex;
     if (mode == 1) { ex.sig_range = sig; ex.save_range = save; ex.sigma_signal = ssig; ex.sigvals = sigvals; ex.nsave_ld = nsave_ld; }
+    const size_t NC = (size_t)HMCG_CORR_COLUMNS(K);
+    double* corr = NULL;
+    if (mode == 4) { corr = calloc((size_t)W * NC * NC, 8); ex.corr = corr; }
 
     double* mu = calloc(W * K * nd, 8); double* sig2 = calloc(W * K * nd, 8); double* A = calloc(W * K * K * nd, 8);
     double* pe = calloc(W * K * nd, 8); double* fc = calloc(W * 2 * (H ? H : 1) * nd, 8); double* sm = calloc(W * NS, 8);
@@ -113,6 +117,7 @@ int main(int argc, char** argv)
     int bad = wr(f, mu, W * K * nd * 8) || wr(f, sig2, W * K * nd * 8) || wr(f, A, W * K * K * nd * 8) || wr(f, pe, W * K * nd * 8) ||
               wr(f, fc, W * 2 * H * nd * 8) || wr(f, sm, W * NS * 8) || wr(f, st, W * 4);
     if (mode == 1) bad = bad || wr(f, sigvals, (size_t)W * (n_samples > 1 ? n_samples : 1) * nsave_ld * 8);
+    if (mode == 4) bad = bad || wr(f, corr, (size_t)W * NC * NC * 8);
     fclose(f);
     printf("cdriver ok: mode %d, %d windows, %d launches, kernel %.3f ms, call %.3f ms\n", mode, W, tm[0].launches, tm[0].kernel_ms, tm[0].call_ms);
     return bad ? 7 : 0;

@@ -55,7 +55,8 @@ def run_driver(tmp_path, mode, Y, Tw, K, burnin, nrun, horizons, yreal, n_sample
     out, off = {}, 0
     for name, shape, dt in (("mu", (W, K, nd), "<f8"), ("sig2", (W, K, nd), "<f8"), ("A", (W, K, K, nd), "<f8"),
                             ("pi_end", (W, K, nd), "<f8"), ("fcast", (W, 2 * H, nd), "<f8"), ("summary", (W, NS), "<f8"),
-                            ("status", (W,), "<i4")) + ((("sigvals", (W, max(n_samples, 1), nsave_ld), "<f8"),) if mode == 1 else ()):
+                            ("status", (W,), "<i4")) + ((("sigvals", (W, max(n_samples, 1), nsave_ld), "<f8"),) if mode == 1 else ()) \
+            + ((("corr", (W, 3 * K + K * K + 1, 3 * K + K * K + 1), "<f8"),) if mode == 4 else ()):
         n = int(np.prod(shape)) * np.dtype(dt).itemsize
         out[name] = raw[off:off + n].view(dt).reshape(shape)
         off += n
@@ -106,3 +107,18 @@ def test_c_driver_multi_device_entry_one_device(hmclib, oracle, tmp_path):
     g, _ = run_driver(tmp_path, 2, Y, Tw, 3, 4, 20, (1, 12), fut[:, [0, 11]], n_devices=1)
     for w in range(len(lens)):
         check(g, oracle.estimate_window(Y[w, :Tw[w]], 3, 4, 20, (1, 12), fut[w, [0, 11]], window_id=w), w)
+
+
+def test_c_driver_correlation_matrices(tmp_path):
+    """extras.corr from plain C (mode 4): the matrices calccorr builds (src/Hmc.jl:1094-1163), taken on the device, against
+    numpy.corrcoef of the 5-digit-rounded draws the same call returned."""
+    K, W, T, nrun = 3, 3, 300, 900
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    out, _ = run_driver(tmp_path, 4, Y, Tw, K, 30, nrun, (12,), fut[:, 11:12])
+    assert (out["status"] == 0).all()
+    for w in range(W):
+        cols = np.concatenate([out["mu"][w], out["sig2"][w], out["pi_end"][w], out["A"][w].reshape(K * K, nrun), out["fcast"][w][:1]])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            exp = np.corrcoef(np.round(cols, 5))
+        ok = np.isfinite(exp)
+        assert np.array_equal(np.isfinite(out["corr"][w]), ok) and np.abs(out["corr"][w][ok] - exp[ok]).max() < 1e-10
