@@ -60,14 +60,15 @@ def usable_cores(omp_max):
 def cpu_baseline(Y, Tw, yreal):
     """The oracle (kind "port": C restatement of the reference's CPU path) timed on the
     host cores over a bounded sample of the same workload: 2 windows per core, draws per
-    window sized from a calibration run to ~8 s of wall time."""
+    window sized from a single-thread calibration run to ~12 s of wall time (plus ~1.5 s for the
+    "faithful cost" variant)."""
     from oracle import oracle
     cores = usable_cores(oracle.max_threads())
     nwin = min(2 * cores, Y.shape[0])
     t0 = time.perf_counter()
     oracle.estimate_batch(Y[:1], Tw[:1], K, 0, 200, (HORIZON,), yreal[:1], nthreads=1)
     rate1 = 200 / (time.perf_counter() - t0)
-    n = int(min(20000, max(200, 8.0 * rate1 * cores / nwin)))
+    n = int(min(400000, max(200, 12.0 * rate1 * cores / nwin)))
     t0 = time.perf_counter()
     oracle.estimate_batch(Y[:nwin], Tw[:nwin], K, 0, n, (HORIZON,), yreal[:nwin], nthreads=cores)
     dt = time.perf_counter() - t0
@@ -181,6 +182,51 @@ def end_to_end_record(Y, Tw, yreal, reps=7):
                    "hmcg_estimate_batch; c_caller is the same call from tests/cdriver (plain C, no Python)"}
     rec["c_caller"] = c_caller_record(Y, Tw, yreal)
     return rec
+
+
+def sustained_record(panel, ids0, seconds=2.5):
+    """Back-to-back launches of the headline shape for >= `seconds` (the 20 timed steps of the headline region last 0.1 s:
+    they say nothing about the clock the chip holds under this kernel for seconds; MI355X_MICROARCH.md, DVFS give-back).
+    Launches are enqueued untimed on the library stream; wall time between two device synchronisations."""
+    import torch
+    one = panel.run(burnin=0, seed=1234, window_base=ids0, timed=True)
+    n = max(20, int(seconds * 1e3 / one) + 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        panel.run(burnin=0, seed=1234, window_base=ids0, timed=False)
+    panel.sync()
+    dt = time.perf_counter() - t0
+    last = panel.run(burnin=0, seed=1234, window_base=ids0, timed=True)      # HIP-event time of the launch right after
+    return {"launches": n, "seconds": dt, "ms_per_launch": dt / n * 1e3, "value": W_PER_GPU * DRAWS * n / dt,
+            "unit": "Gibbs draws/s", "kernel_ms_after": last, "first_kernel_ms": one,
+            "note": "%d launches enqueued back to back, wall clock between synchronisations (launch gaps included)" % n}
+
+
+def alu_roofline(kernel_ms, key):
+    """The roofline that actually binds these kernels: VALU issue.  A SIMD issues one wave-instruction of a lone wave per
+    4 shader cycles (fp64 FMA included: tools/ubench/clock.hip measures 4.03 cycles per fp64 wave-op with every CU busy,
+    i.e. the 78.6 TFLOP/s vector peak at 2.4 GHz), so a launch cannot take less than
+        VALU wave-instructions / (CUs x 4 SIMDs) x 4 cycles / clock.
+    Instruction counts come from the SQ_INSTS_VALU pass kept under profiles/ (same launch shape), the clock from the
+    in-kernel s_memtime / s_memrealtime ratio of the stamped build after >= 2 s of launches (profiles/clock.json)."""
+    try:
+        ck = json.load(open(os.path.join(ROOT, "profiles", "clock.json")))[key]
+    except Exception:
+        return None
+    insts, mhz = ck.get("valu_wave_insts_per_launch"), ck.get("clock_mhz")
+    if not insts or not mhz:
+        return None
+    simds = 256 * 4
+    bound_ms = insts / simds * 4.0 / (mhz * 1e6) * 1e3
+    fp64 = ck.get("fp64_flop_per_launch")
+    out = {"bound": "valu_issue", "valu_wave_insts_per_launch": insts, "in_kernel_clock_mhz": mhz,
+           "cycles_per_wave_inst": 4.0, "issue_bound_ms": bound_ms, "kernel_ms": kernel_ms, "frac": bound_ms / kernel_ms,
+           "source": ck.get("source")}
+    if fp64:
+        tf = fp64 / (kernel_ms * 1e-3) / 1e12
+        out.update({"fp64_TFLOPs": tf, "fp64_vector_peak_TFLOPs": 78.6, "frac_of_fp64_peak": tf / 78.6})
+    return out
 
 
 def spawn_ranks(args):
@@ -304,15 +350,36 @@ def main():
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "kernel": kernel_name(K, tm),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": B * W_PER_GPU * DRAWS,
+                         "model_GBps": achieved,
+                         "measured_hbm_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "note": "algorithmic bytes = 58160 B/draw (SURVEY 8d) x 256 windows x 1000 draws; the chain "
                                  "state is register/LDS-resident, so the physical limiter is fp64 VALU issue, not HBM"},
         }
+        ra = alu_roofline(k_ms, "headline")
+        if ra:
+            line["roofline_alu"] = ra
         if world == 1 and not args.no_extra:
-            del panel
             extra = {}
             try:
-                extra["end_to_end_host_entry"] = end_to_end_record(Y, Tw, yreal)
+                extra["sustained"] = sustained_record(panel, ids[0])
+            except Exception as e:
+                extra["sustained_error"] = repr(e)
+            del panel
+            try:
+                e2e = end_to_end_record(Y, Tw, yreal)
+                extra["end_to_end_host_entry"] = e2e
+                # SURVEY 8(d)'s wall-clock definition (H2D of Y + kernels + D2H of every per-draw output) beside `value`,
+                # which the bench contract defines with the inputs resident in HBM
+                cc = e2e.get("c_caller", {})
+                ms_e2e = cc.get("ms_per_call", e2e["ms_per_call"])
+                line["end_to_end"] = {"value": W_PER_GPU * DRAWS / (ms_e2e * 1e-3), "unit": "Gibbs draws/s", "ms_per_call": ms_e2e,
+                                      "caller": "plain C (tests/cdriver)" if "ms_per_call" in cc else "python ctypes",
+                                      "device_resident_ms": k_ms, "overhead_vs_device_resident": ms_e2e / k_ms - 1.0,
+                                      "definition": "SURVEY 8(d): pageable host Y in, all per-draw outputs (41 MB) back in the caller's arrays"}
                 extra["cfg4_k8_T5000_w512"] = shape_record("configs[3]: 8-state, T=5000, 512 windows, 1000 draws", 8, [5000] * 512, 1000, reps=2)
+                ra8 = alu_roofline(extra["cfg4_k8_T5000_w512"]["kernel_ms"], "k8")
+                if ra8:
+                    extra["cfg4_k8_T5000_w512"]["roofline_alu"] = ra8
                 extra["production_460_expanding"] = shape_record(
                     "the reference's production shape (code/run_hmm.jl:79-109): 460 expanding windows T=120..579, K=3, 1000 draws",
                     3, list(range(120, 580)), 1000)

@@ -469,6 +469,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     unsigned long long stamp_acc[HMCG_NSTAMP];
     for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int sweep = p.sweep_begin; sweep < p.sweep_end; ++sweep) {
         rng.sweep = (uint32_t)sweep;
@@ -973,8 +974,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         STAMP(13);
     }
 #ifdef HMCG_STAMPS
-    if (lane == 0 && p.dbg)
-        for (int i = 0; i < HMCG_NSTAMP; ++i) p.dbg[((size_t)w * NW + wave) * HMCG_NSTAMP + i] = stamp_acc[i];
+    if (lane == 0 && p.dbg) {
+        unsigned long long* o = p.dbg + ((size_t)w * NW + wave) * HMCG_NSTAMP_ALL;
+        for (int i = 0; i < HMCG_NSTAMP; ++i) o[i] = stamp_acc[i];
+        o[HMCG_NSTAMP] = __builtin_amdgcn_s_memtime() - stamp_t0;
+        o[HMCG_NSTAMP + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
 #endif
 
     // ---- epilogue ----

@@ -745,6 +745,7 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 // through p.dbg, which no other code reads.
 #ifdef HMCG_STAMPS
 #define HMCG_NSTAMP 20
+#define HMCG_NSTAMP_ALL (HMCG_NSTAMP + 2)   // + the sweep loop's total in s_memtime ticks and in s_memrealtime (100 MHz) ticks
 #define STAMP(i)                                                          \
     do {                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                \
@@ -1386,6 +1387,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #ifdef HMCG_STAMPS
     for (int i = 0; i < HMCG_NSTAMP; ++i) stamp_acc[i] = 0;
     stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     if constexpr (NH > 0) {
@@ -1993,8 +1995,12 @@ void gibbs_sweeps_kernel(const KernelParams p)
         STAMP(13);
     }
 #ifdef HMCG_STAMPS
-    if (lane == 0 && p.dbg)
-        for (int i = 0; i < HMCG_NSTAMP; ++i) p.dbg[((size_t)w * (NW + NH) + wave) * HMCG_NSTAMP + i] = stamp_acc[i];
+    if (lane == 0 && p.dbg) {
+        unsigned long long* o = p.dbg + ((size_t)w * (NW + NH) + wave) * HMCG_NSTAMP_ALL;
+        for (int i = 0; i < HMCG_NSTAMP; ++i) o[i] = stamp_acc[i];
+        o[HMCG_NSTAMP] = __builtin_amdgcn_s_memtime() - stamp_t0;             // in-kernel clock = ticks / realtime ticks * 100 MHz
+        o[HMCG_NSTAMP + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
 #endif
 
     // ---- epilogue: the last sweep's outputs, checkpoint / debug outputs ----

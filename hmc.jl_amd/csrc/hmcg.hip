@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_util.hpp"
 #include "moments.hpp"
 #include "variants.hpp"
 
@@ -89,66 +90,6 @@ struct Layout {
 
 constexpr int RING = 3;            // chunk buffers in flight (device and pinned)
 
-// A few persistent host threads that share the scatter of a chunk (pinned staging -> the caller's arrays: 41 MB per call
-// at the headline shape, as many small memcpys) with the calling thread.  On hosts whose single-thread copy rate is below
-// the device's draw rate the scatter, not the GPU, would otherwise set the pace of the host entry.
-class ScatterPool {
-public:
-    ~ScatterPool() { if (!th_.empty()) stop(); }
-    void start(int workers)
-    {
-        if (!th_.empty() || workers <= 0) return;
-        for (int i = 0; i < workers; ++i) th_.emplace_back([this, i] { loop(i); });
-    }
-    void stop()
-    {
-        { std::lock_guard<std::mutex> lk(m_); quit_ = true; ++gen_; }
-        go_.notify_all();
-        for (auto& t : th_) t.join();
-        th_.clear();
-        quit_ = false;
-    }
-    // f(part, nparts) for part = 0..nparts-1, nparts = workers + 1; returns when every part is done
-    void run(const std::function<void(int, int)>& f)
-    {
-        const int np = (int)th_.size() + 1;
-        if (np == 1) { f(0, 1); return; }
-        { std::lock_guard<std::mutex> lk(m_); job_ = &f; pending_ = np - 1; ++gen_; }
-        go_.notify_all();
-        f(np - 1, np);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
-        job_ = nullptr;
-    }
-private:
-    void loop(int id)
-    {
-        unsigned long seen = 0;
-        for (;;) {
-            const std::function<void(int, int)>* f;
-            int np;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                go_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (quit_) return;
-                f = job_;
-                np = (int)th_.size() + 1;
-            }
-            if (f) (*f)(id, np);
-            { std::lock_guard<std::mutex> lk(m_); --pending_; }
-            done_.notify_one();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable go_, done_;
-    const std::function<void(int, int)>* job_ = nullptr;
-    unsigned long gen_ = 0;
-    int pending_ = 0;
-    bool quit_ = false;
-};
-
 struct DeviceCtx {
     std::mutex mu;                 // serialises calls on this device
     bool ready = false;
@@ -161,7 +102,7 @@ struct DeviceCtx {
     Arena dev, pin;
     Arena mom;                     // device entry: the draw-moment tables behind extras.corr
     Arena scr;                     // device entry: the LDS-resident kernel's pdf scratch
-    ScatterPool pool;              // host entries: helpers for the scatter into the caller's arrays
+    hmcg_hostutil::ScatterPool pool;              // host entries: helpers for the scatter into the caller's arrays
 };
 DeviceCtx g_ctx[HMCG_MAXDEV];
 std::mutex g_init_mu;
@@ -231,6 +172,7 @@ void destroy_context(DeviceCtx& c)
 }
 
 using namespace hmcg_host;
+using namespace hmcg_hostutil;
 int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
 const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
 
@@ -413,8 +355,27 @@ int print_stamps(const hmcg::KernelParams& p, const Plan& pl, unsigned long long
     const int nwv = pl.NT() / 64 + pl.NH();
     std::vector<unsigned long long> h(ndbg);
     HIP_TRY(hipStreamSynchronize(stream));
+    // HMCG_STAMPS_AFTER=n: stay silent for the first n launches (tools/stamps.py warms the chip up for >= 2 s first)
+    static int launches_seen = 0;
+    static const int print_after = getenv("HMCG_STAMPS_AFTER") ? atoi(getenv("HMCG_STAMPS_AFTER")) : 0;
+    if (launches_seen++ < print_after) return 0;
     HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     const int nsw = p.sweep_end - p.sweep_begin;
+    {
+        // in-kernel clock of every wave: d(s_memtime) / d(s_memrealtime) * 100 MHz around the sweep loop
+        std::vector<double> clk;
+        double ticks = 0;
+        for (int w = 0; w < p.W; ++w)
+            for (int wv = 0; wv < nwv; ++wv) {
+                const unsigned long long* o = &h[((size_t)w * nwv + wv) * HMCG_NSTAMP_ALL];
+                if (o[HMCG_NSTAMP + 1]) { clk.push_back(100.0 * (double)o[HMCG_NSTAMP] / (double)o[HMCG_NSTAMP + 1]); ticks += (double)o[HMCG_NSTAMP]; }
+            }
+        std::sort(clk.begin(), clk.end());
+        if (!clk.empty())
+            fprintf(stderr, "[clock] launch %d: in-kernel clock MHz min %.0f median %.0f max %.0f (s_memtime / s_memrealtime x 100 MHz); "
+                            "%.0f ticks per sweep (mean over waves)\n", launches_seen - 1, clk.front(), clk[clk.size() / 2], clk.back(),
+                    ticks / (double)clk.size() / (nsw > 0 ? nsw : 1));
+    }
     fprintf(stderr, "[stamps] K=%d L=%d NT=%d W=%d sweeps=%d: mean cycles per sweep by wave (s_memtime ticks)\n",
             pl.v ? pl.v->K : pl.bv->K, pl.L(), pl.NT(), p.W, nsw);
     fprintf(stderr, "%-24s", "phase");
@@ -425,7 +386,7 @@ int print_stamps(const hmcg::KernelParams& p, const Plan& pl, unsigned long long
         fprintf(stderr, "%-24s", names[i]);
         for (int wv = 0; wv < nwv; ++wv) {
             double acc = 0;
-            for (int w = 0; w < p.W; ++w) acc += (double)h[((size_t)w * nwv + wv) * HMCG_NSTAMP + i];
+            for (int w = 0; w < p.W; ++w) acc += (double)h[((size_t)w * nwv + wv) * HMCG_NSTAMP_ALL + i];
             acc /= (double)p.W * (nsw > 0 ? nsw : 1);
             tot[wv] += acc;
             fprintf(stderr, " %8.0f", acc);
@@ -482,7 +443,7 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
     }
     if (timing) HIP_TRY(hipEventRecord(c.ev0, stream));
 #ifdef HMCG_STAMPS
-    const size_t ndbg = (size_t)cfg->W * (pl.NT() / 64 + pl.NH()) * HMCG_NSTAMP;
+    const size_t ndbg = (size_t)cfg->W * (pl.NT() / 64 + pl.NH()) * HMCG_NSTAMP_ALL;
     unsigned long long* ddbg = nullptr;
     HIP_TRY(hipMalloc((void**)&ddbg, ndbg * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(ddbg, 0, ndbg * sizeof(unsigned long long), stream));
@@ -516,49 +477,6 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
 }
 
 // ---- host entry on one device --------------------------------------------------------------------------------
-
-// kept draws produced by the sweeps [0, g) of the sampling schedule (n_samples blocks of burnin + nrun sweeps)
-long long kept_before(long long g, int per, int burnin, int nrun)
-{
-    const long long smp = g / per, i = g - smp * per;
-    return smp * nrun + std::max(0LL, std::min((long long)nrun, i - burnin));
-}
-// global sweep index just after kept draw number d - 1 (d >= 1) has been produced
-long long sweep_after_kept(long long d, int per, int burnin, int nrun)
-{
-    const long long smp = (d - 1) / nrun, i = (d - 1) - smp * nrun;
-    return smp * per + burnin + i + 1;
-}
-
-struct Chunk { int s0, s1; long long d0, d1; };   // sweeps [s0, s1) produce the kept draws [d0, d1)
-
-// Chunks of the sweep range [sb, se): draw counts halve from chunk to chunk down to ~1/32 of the run (the last chunk's
-// copy-out is the only one not hidden behind sampling; HMCG_CHUNK_FLOOR_DIV overrides the 32), never more than `cap`
-// draws in a chunk.
-std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int nrun, long long cap, bool stream_draws)
-{
-    std::vector<Chunk> out;
-    const long long dB = kept_before(sb, per, burnin, nrun), dE = kept_before(se, per, burnin, nrun);
-    const long long nd = dE - dB;
-    if (!stream_draws || nd <= 0 || se <= sb) { out.push_back({sb, se, dB, dE}); return out; }
-    long long fdiv = 32;       // (measured at the headline shape: 1/8 5.34 ms, 1/16 5.30, 1/32 5.23 per call)
-    if (const char* e = getenv("HMCG_CHUNK_FLOOR_DIV")) { const long long v = atoll(e); if (v >= 2 && v <= 1024) fdiv = v; }
-    const long long floor_sz = std::max(16LL, nd / fdiv);
-    long long d = dB;
-    int s = sb;
-    while (d < dE) {
-        const long long rem = dE - d;
-        long long take = std::min(cap, std::max((rem + 1) / 2, floor_sz));
-        if (rem - take < floor_sz / 2) take = std::min(cap, rem);       // no crumbs
-        take = std::min(take, rem);
-        const long long d1 = d + take;
-        const int s1 = d1 == dE ? se : (int)sweep_after_kept(d1, per, burnin, nrun);
-        out.push_back({s, s1, d, d1});
-        d = d1; s = s1;
-    }
-    if (out.back().s1 != se) out.back().s1 = se;
-    return out;
-}
 
 struct HostArrays {
     const double* Y; const int32_t* T; const double* yreal;
@@ -699,6 +617,9 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (want_fm) H2D(o_dfm, o_pfm, 8 * N * ld * K);
     } else {
         HIP_TRY(hipMemsetAsync(D + o_dst, 0, 4 * N, s));
+        // the checkpoint blocks live in the recycled arena: a skipped window writes neither, and must not hand the
+        // caller an earlier call's bytes
+        if (need_ckpt) { HIP_TRY(hipMemsetAsync(D + o_dxs, 0, N * ld, s)); HIP_TRY(hipMemsetAsync(D + o_dacc, 0, 8 * N * (NS + K), s)); }
         if (want_sm) HIP_TRY(hipMemsetAsync(D + o_dsm, 0, 8 * N * ld * K, s));
         if (want_fm) HIP_TRY(hipMemsetAsync(D + o_dfm, 0, 8 * N * ld * K, s));
     }
@@ -859,29 +780,6 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         fill_timing(timing, pl, c, kernel_ms, nch, call_ms, n);
     }
     return 0;
-}
-
-// Static LPT partition (as hmc.jl_amd/shard.py partition_windows): windows by length, longest first (stable), each to
-// the lightest device that still has room under the count cap ceil(W / G).
-std::vector<std::vector<int32_t>> partition_windows(const int32_t* T, int W, int G)
-{
-    std::vector<int32_t> order((size_t)W);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return T[a] > T[b]; });
-    std::vector<long long> load((size_t)G, 0);
-    std::vector<int> count((size_t)G, 0);
-    std::vector<std::vector<int32_t>> parts((size_t)G);
-    const int cap = (W + G - 1) / G;
-    for (int32_t w : order) {
-        int best = -1;
-        for (int r = 0; r < G; ++r)
-            if (count[(size_t)r] < cap && (best < 0 || load[(size_t)r] < load[(size_t)best])) best = r;
-        parts[(size_t)best].push_back(w);
-        load[(size_t)best] += T[w];
-        ++count[(size_t)best];
-    }
-    for (auto& p : parts) std::sort(p.begin(), p.end());
-    return parts;
 }
 
 }  // namespace

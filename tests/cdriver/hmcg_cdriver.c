@@ -79,12 +79,17 @@ int main(int argc, char** argv)
         }
         /* per-call wall times; the median is reported (a host thread that gets descheduled once costs a mean 10 %) */
         double* tc = calloc((size_t)reps, 8);
+        double* mu_ref = calloc(W * K * nd, 8);
         double sum = 0.0;
         for (int i = 0; i < reps; ++i) {
             const double t0 = now_ms();
             rc = hmcg_estimate_batch(&cfg, Y, T, yreal, mu, sig2, A, pe, fc, sm, st, NULL, NULL);
             tc[i] = now_ms() - t0;
             sum += tc[i];
+            /* a failing (early-returning) call must not be reported as a fast one; nor one whose draws changed */
+            if (rc) { fprintf(stderr, "libhmcgibbs rc=%d in timed call %d: %s\n", rc, i, hmcg_last_error()); return 5; }
+            if (i == 0) memcpy(mu_ref, mu, W * K * nd * 8);
+            else if (i == reps - 1 && memcmp(mu_ref, mu, W * K * nd * 8)) { fprintf(stderr, "timed call %d: draws differ from the first\n", i); return 6; }
         }
         for (int i = 1; i < reps; ++i)                          /* insertion sort */
             for (int j = i; j > 0 && tc[j - 1] > tc[j]; --j) { const double x = tc[j]; tc[j] = tc[j - 1]; tc[j - 1] = x; }
