@@ -93,7 +93,8 @@ constexpr int RING = 3;            // chunk buffers in flight (device and pinned
 struct DeviceCtx {
     std::mutex mu;                 // serialises calls on this device
     bool ready = false;
-    int device = -1;
+    int device = -1;               // the id callers use (cfg->device, device_ids[])
+    int phys = -1;                 // the HIP device behind it (== device unless HMCG_VIRTUAL_DEVICES is set)
     hipStream_t stream = nullptr, copy = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;          // kernel timing
     hipEvent_t ev_scr = nullptr;                      // device entry: last use of the shared scratch (scr, mom) on any stream
@@ -107,7 +108,17 @@ struct DeviceCtx {
 DeviceCtx g_ctx[HMCG_MAXDEV];
 std::mutex g_init_mu;
 
-// Returns the (created on first use) context of `device`; the caller then locks ctx->mu and calls hipSetDevice.
+// HMCG_VIRTUAL_DEVICES=n (diagnostics): the library offers n device ids, id i living on physical device i mod
+// (physical count), each with its own context -- streams, arenas, scatter helpers.  It lets a one-GPU box execute the
+// G > 1 branch of hmcg_estimate_batch_multi (worker threads, per-context workspaces, error aggregation) that otherwise
+// needs a multi-GPU node.  0 / unset: ids are physical devices.
+int virtual_devices()
+{
+    static const int v = [] { const char* e = getenv("HMCG_VIRTUAL_DEVICES"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, (int)HMCG_MAXDEV) : 0; }();
+    return v;
+}
+
+// Returns the (created on first use) context of `device`; the caller then locks ctx->mu and calls hipSetDevice(ctx->phys).
 int get_context(int device, DeviceCtx** out)
 {
     int n = 0;
@@ -115,6 +126,8 @@ int get_context(int device, DeviceCtx** out)
         set_err("no HIP device available (libhmcgibbs has no CPU fallback)");
         return HMCG_E_NODEVICE;
     }
+    const int nphys = n;
+    if (virtual_devices() > 0) n = virtual_devices();
     if (device < 0 || device >= n || device >= HMCG_MAXDEV) {
         set_err("device %d out of range (count %d, at most %d)", device, n, HMCG_MAXDEV);
         return HMCG_E_BADARG;
@@ -122,7 +135,8 @@ int get_context(int device, DeviceCtx** out)
     DeviceCtx& c = g_ctx[device];
     std::lock_guard<std::mutex> lk(g_init_mu);
     if (!c.ready) {
-        HIP_TRY(hipSetDevice(device));
+        c.phys = device % nphys;
+        HIP_TRY(hipSetDevice(c.phys));
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&c.ev0));
@@ -132,7 +146,7 @@ int get_context(int device, DeviceCtx** out)
             HIP_TRY(hipEventCreateWithFlags(&c.evk[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.evc[i], hipEventDisableTiming));
         }
-        HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, device));
+        HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, c.phys));
         c.pin.pinned = true;
         {
             // HMCG_SCATTER_THREADS: helper threads per device for the host-side scatter (default 3, 0 = the caller alone)
@@ -152,7 +166,7 @@ int get_context(int device, DeviceCtx** out)
 void destroy_context(DeviceCtx& c)
 {
     if (!c.ready) return;
-    (void)hipSetDevice(c.device);
+    (void)hipSetDevice(c.phys);
     (void)hipStreamSynchronize(c.stream);        // nothing of ours may still be running when the streams go
     (void)hipStreamSynchronize(c.copy);
     (void)hipStreamDestroy(c.stream);
@@ -168,7 +182,7 @@ void destroy_context(DeviceCtx& c)
     c.pool.stop();
     c.stream = c.copy = nullptr;
     c.ready = false;
-    c.device = -1;
+    c.device = c.phys = -1;
 }
 
 using namespace hmcg_host;
@@ -489,6 +503,11 @@ struct HostArrays {
 int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx, int n, const HostArrays& h, hmcg_timing* timing)
 {
     const auto t_call = std::chrono::steady_clock::now();
+    // HMCG_FAIL_DEVICE=id (diagnostics): the host entry fails on that device id before it touches anything -- lets a test
+    // see hmcg_estimate_batch_multi report one worker's error while the others complete
+    if (const char* fe = getenv("HMCG_FAIL_DEVICE")) {
+        if (atoi(fe) == c.device) { set_err("injected failure (HMCG_FAIL_DEVICE=%d)", c.device); return HMCG_E_NOMEM; }
+    }
     Plan pl;
     int rc = make_plan(cfg, h.ex, n, c.cu_count, &pl);
     if (rc) return rc;
@@ -792,6 +811,7 @@ int hmcg_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    if (n > 0 && virtual_devices() > 0) return virtual_devices();
     return n;
 }
 
@@ -818,7 +838,7 @@ int hmcg_estimate_batch_device(const hmcg_config* cfg, const double* dY, const i
     rc = get_context(cfg->device, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipSetDevice(c->phys));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return launch_device(*c, cfg, dY, dT, dyreal, dmu, dsig2, dA, dpi_end, dfcast, dsummary, dstatus, dextras, s, timing);
 }
@@ -834,7 +854,7 @@ int hmcg_estimate_batch(const hmcg_config* cfg, const double* Y, const int32_t* 
     rc = get_context(cfg->device, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipSetDevice(c->phys));
     const HostArrays h{Y, T, yreal, mu, sig2, A, pi_end, fcast, summary, status, extras};
     return run_host_on_device(*c, cfg, nullptr, cfg->W, h, timing);
 }
@@ -865,8 +885,8 @@ int hmcg_estimate_batch_multi(const hmcg_config* cfg, int32_t n_devices, const i
         int rr = get_context(devs[(size_t)r], &c);
         if (!rr) {
             std::lock_guard<std::mutex> lk(c->mu);
-            hipError_t e = hipSetDevice(c->device);
-            if (e != hipSuccess) { set_err("hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e)); rr = (int)e; }
+            hipError_t e = hipSetDevice(c->phys);
+            if (e != hipSuccess) { set_err("hipSetDevice(%d) failed: %s", c->phys, hipGetErrorString(e)); rr = (int)e; }
             else rr = run_host_on_device(*c, cfg, parts[(size_t)r].data(), (int)parts[(size_t)r].size(), h, timing ? timing + r : nullptr);
         }
         rcs[(size_t)r] = rr;

@@ -1,0 +1,31 @@
+"""bench.py's multi-rank path on the one GPU this box has: `--gpus 2 --rehearse-shared-gpu` starts two
+fresh ranks through torch.distributed.run (rendezvous on 127.0.0.1), both on cuda:0, process group gloo (RCCL refuses two
+ranks on one device) -- every line of the N > 1 path except the backend name: global window ids per rank, the gather of
+the summary blocks to rank 0, barrier + synchronize fences, MAX over ranks, rank 0's JSON line relayed by the parent.
+The numbers of a rehearsal are never reported (`"rehearsal": true`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_on_the_shared_gpu(hmclib):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=540)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rehearsal"] is True and rec["steps"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["windows_flagged"] == 0 and rec["config"]["windows_per_gpu"] == 256
+    # whole-job aggregate over both ranks: 2 x 256 windows x 1000 draws x 2 steps in the MAX-over-ranks time
+    assert abs(rec["value"] - 2 * 256 * 1000 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-9
+    assert rec["value"] > 1e6 and "extra" not in rec and "cpu_baseline" not in rec

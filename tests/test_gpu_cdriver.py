@@ -29,7 +29,7 @@ def build_driver():
 
 
 def run_driver(tmp_path, mode, Y, Tw, K, burnin, nrun, horizons, yreal, n_samples=0, kappa=0.0, alpha=0.0, nu=0.0,
-               sig=None, save=None, ssig=None, nsave_ld=0, n_devices=1):
+               sig=None, save=None, ssig=None, nsave_ld=0, n_devices=1, env_extra=None, expect_rc=0):
     W, ld = Y.shape
     H = len(horizons)
     hz = list(horizons) + [0] * (8 - H)
@@ -46,7 +46,11 @@ def run_driver(tmp_path, mode, Y, Tw, K, burnin, nrun, horizons, yreal, n_sample
             f.write(np.ascontiguousarray(save, dtype="<i4").tobytes())
             f.write(np.ascontiguousarray(ssig, dtype="<f8").tobytes())
     env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    env.update(env_extra or {})
     r = subprocess.run([build_driver(), req, resp], capture_output=True, text=True, env=env, timeout=300)
+    if expect_rc:
+        assert r.returncode == expect_rc, (r.returncode, r.stdout, r.stderr)
+        return None, r.stdout + r.stderr
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "cdriver ok" in r.stdout
     nd = max(n_samples, 1) * nrun
@@ -107,6 +111,36 @@ def test_c_driver_multi_device_entry_one_device(hmclib, oracle, tmp_path):
     g, _ = run_driver(tmp_path, 2, Y, Tw, 3, 4, 20, (1, 12), fut[:, [0, 11]], n_devices=1)
     for w in range(len(lens)):
         check(g, oracle.estimate_window(Y[w, :Tw[w]], 3, 4, 20, (1, 12), fut[w, [0, 11]], window_id=w), w)
+
+
+def test_multi_entry_four_virtual_devices_equals_single_device(hmclib, oracle, tmp_path):
+    """The G > 1 branch of hmcg_estimate_batch_multi -- worker threads, one context (streams, arenas, scatter helpers) per
+    device id, LPT partition, error aggregation -- on a one-GPU box: HMCG_VIRTUAL_DEVICES=4 maps four device ids onto the
+    one physical device.  Ragged windows, enough draws that every worker's chunks go through its scatter helpers; the
+    result must equal the single-device call bit for bit (global RNG ids) and the oracle within 1e-9.
+    Reference role: the SLURM fan-out, slurmscripts/base_estimation.sh:5,17."""
+    lens = [500, 120, 333, 64, 257, 480, 199, 401, 77, 350, 512]
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), 3, ragged=lens)
+    one, _ = run_driver(tmp_path, 2, Y, Tw, 3, 4, 3000, (1, 12), fut[:, [0, 11]], n_devices=1)
+    four, log = run_driver(tmp_path, 2, Y, Tw, 3, 4, 3000, (1, 12), fut[:, [0, 11]], n_devices=4,
+                           env_extra={"HMCG_VIRTUAL_DEVICES": "4", "HMCG_CHUNK_DRAWS": "1500"})
+    for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "status"):
+        assert np.array_equal(one[k], four[k]), k
+    for w in (0, 3, 10):
+        check(four, oracle.estimate_window(Y[w, :Tw[w]], 3, 4, 3000, (1, 12), fut[w, [0, 11]], window_id=w), w)
+    # more devices than the box offers without the switch: refused, not silently folded
+    _, msg = run_driver(tmp_path, 2, Y, Tw, 3, 4, 20, (1, 12), fut[:, [0, 11]], n_devices=4, expect_rc=5)
+    assert "out of range" in msg
+
+
+def test_multi_entry_reports_the_failing_device(hmclib, tmp_path):
+    """One worker of four fails (HMCG_FAIL_DEVICE: injected before it touches the GPU): the call returns that device's
+    error, named, after the other workers have finished."""
+    lens = [300, 200, 250, 150, 280, 120, 90, 310]
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), 3, ragged=lens)
+    _, msg = run_driver(tmp_path, 2, Y, Tw, 3, 2, 50, (12,), fut[:, 11:12], n_devices=4, expect_rc=5,
+                        env_extra={"HMCG_VIRTUAL_DEVICES": "4", "HMCG_FAIL_DEVICE": "2"})
+    assert "device 2: injected failure" in msg, msg
 
 
 def test_c_driver_correlation_matrices(tmp_path):

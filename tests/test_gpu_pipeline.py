@@ -128,3 +128,20 @@ def test_workspaces_survive_shape_changes(hmclib):
     _lib.load().hmcg_shutdown()                     # contexts are rebuilt on demand
     again = _lib.estimate_batch_host(Y[:3], Tw[:3], 3, 3, 50, (12,), fut[:3, 11:12])
     assert np.array_equal(again["mu"], small["mu"])
+
+
+def test_shutdown_then_large_call_scatters_every_chunk(hmclib):
+    """After hmcg_shutdown() the scatter helpers are new threads while the pool's generation counter has moved on: a
+    fresh worker must neither run a phantom job nor be counted as done for one (`run()` could return while a
+    helper was still copying into the caller's arrays).  Chunks above the 1 MiB hand-off threshold, twice, against the
+    single-threaded scatter."""
+    import os
+    Y, Tw, fut = synth.generate_panel(96, 400, 3)
+    args = (Y, Tw, 3, 2, 1200, (12,), fut[:, 11:12])           # 96 x 20 x 600 x 8 B = 9 MB in the first chunk
+    ref = _lib.estimate_batch_host(*args)
+    for _ in range(3):
+        _lib.load().hmcg_shutdown()
+        r = _lib.estimate_batch_host(*args)
+        assert r["launches"] >= 3
+        for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary"):
+            assert np.array_equal(r[k], ref[k]), k
