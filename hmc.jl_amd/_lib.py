@@ -47,7 +47,7 @@ class Extras(C.Structure):
                 ("sig_range", C.c_void_p), ("save_range", C.c_void_p), ("sigma_signal", C.c_void_p),
                 ("sigvals", C.c_void_p), ("nsave_ld", C.c_int32), ("reserved2", C.c_int32),
                 ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p), ("pi_filter_mean", C.c_void_p),
-                ("corr", C.c_void_p)]
+                ("corr", C.c_void_p), ("sample_summary", C.c_void_p)]
 
 
 class Timing(C.Structure):
@@ -154,7 +154,8 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         threads_per_window=0, x_init=None, want_state=False, want_draws=True, alpha=0.0, nu=0.0,
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
-                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None, want_corr=False):
+                        end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None, want_corr=False,
+                        want_sample_summary=False, resume_sample_summary=None):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,).
@@ -163,7 +164,10 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     buffers, as a Julia or C caller does, pays no allocation or first-touch page faults per call).
     want_corr: out["corr"] (W, NC, NC), NC = 3K + K^2 + 1 -- the correlation matrix calccorr (src/Hmc.jl:1094-1163) builds
     per end date from the per-draw CSV files, accumulated on the device from the rounded draws (extras.corr); works with
-    want_draws=False (the draws then never leave the device)."""
+    want_draws=False (the draws then never leave the device).
+    want_sample_summary (signal path): out["sample_summary"] (W, n_samples, NS) -- per noise sample the mean over its kept
+    draws of the 5-digit-rounded outputs (extras.sample_summary: the rows runaggregate makes per (date, signalid));
+    resume_sample_summary carries the buffer of a call that stopped inside a sample into its RESUME call."""
     L = load()
     Y = np.ascontiguousarray(Y, dtype=np.float64)
     W, ldY = Y.shape
@@ -211,6 +215,10 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         if end_pos is not None:                    # signals past the end date (sigLen > 0)
             epos = np.ascontiguousarray(end_pos, dtype=np.int32).reshape(W)
             ex.end_pos = epos.ctypes.data
+    if want_sample_summary:
+        out["sample_summary"] = (np.zeros((W, max(int(n_samples), 1), NS)) if resume_sample_summary is None else
+                                 np.ascontiguousarray(resume_sample_summary, dtype=np.float64).reshape(W, max(int(n_samples), 1), NS).copy())
+        ex.sample_summary = out["sample_summary"].ctypes.data
     if want_smooth:
         out["pi_smooth_mean"] = np.zeros((W, ldY, K))
         ex.pi_smooth_mean = out["pi_smooth_mean"].ctypes.data
@@ -259,7 +267,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     # plausible-looking zero (the reference would have thrown, src/Hmc.jl:435)
     skipped = (out["status"] & ST_SKIPPED) != 0
     if skipped.any():
-        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final", "corr"):
+        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final", "corr", "sample_summary"):
             if name in out:
                 out[name][skipped] = np.nan
     out["kernel_ms"] = tm.kernel_ms

@@ -82,6 +82,9 @@ struct KernelParams {
     double* pi_smooth_mean;
     // the same running sum for the FILTERED probabilities pif[t,:] (sorted labels), [W][ldY][K]; SMOOTH variants
     double* pi_filter_mean;
+    // signal path: per noise sample the mean over its nrun_s kept draws of the rounded outputs, [W][n_samples][NS] (one row
+    // of upstream's runaggregate over a signal run, src/Hmc.jl:1025-1057); the raw running sums while a sample is incomplete
+    double* sample_summary;
     // LDS-resident kernel (gibbs_big.hpp) only: scratch that hands each step's K pdfs from the product phase to the replay,
     // [W][L][K][NT] (thread index fastest: coalesced); library-owned
     double* fscr;
@@ -1014,6 +1017,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
 
     constexpr int FC_SPLIT_MAX = 26;      // beyond this, binary exponentiation (27 log2 h fma) beats 9 h/2
     double sum_acc = 0.0;                 // running sum behind `summary` (meaningful on the output lanes only)
+    double smp_acc = 0.0;                 // signal path: the same sum over the running noise sample (extras.sample_summary)
+    (void)smp_acc;
     constexpr int OUT_WAVE = NH > 0 ? NW + 3 : 1;        // owns the 3K + K^2 parameter output lanes
     constexpr int FC_WAVE = NH > 0 ? NW + 2 : NW - 1;    // owns the 2H forecast lanes (== OUT_WAVE when NW == 2)
     constexpr int PREP_WAVE = NH > 0 ? NW + 1 : (NW - 1 >= 3 ? 2 : 1);   // prepares the next sweep's RNG parts
@@ -1056,9 +1061,16 @@ void gibbs_sweeps_kernel(const KernelParams p)
         }
         typename Sh::OutConst c;
         c.base = out_base; c.yr = fc_yr; c.h = fc_h;
-        c.packed = o_which | (o_q << 4) | (o_i << 8) | (o_j << 12) | (fc_blend << 16) | (orole >= 0 ? (1 << 30) : 0);
+        c.packed = o_which | (o_q << 4) | (o_i << 8) | (o_j << 12) | (fc_blend << 16) | ((orole >= 0 ? orole : 0) << 20) | (orole >= 0 ? (1 << 30) : 0);
         sh.oc[oslot][lane] = c;                            // (read back by the same lane only; the prologue's barriers follow)
         if (orole >= 0 && p.resume && p.sumacc) sum_acc = p.sumacc[(size_t)w * NCK + orole];
+        if constexpr (SIG) {
+            // a launch that resumes inside a noise sample picks that sample's running sums up from its row
+            if (orole >= 0 && p.resume && p.sample_summary) {
+                const int smp = p.sweep_begin / p.per_sample, kb = p.sweep_begin - smp * p.per_sample - p.burnin_s;
+                if (kb > 0 && kb < p.nrun_s && smp < p.n_samples) smp_acc = p.sample_summary[((size_t)w * p.n_samples + smp) * NS + orole];
+            }
+        }
     }
     // per-draw outputs of sweep `sw` (whose parameters sit in sh.th[sw & 1])
     auto job_outputs = [&](int sw) __attribute__((always_inline)) {
@@ -1178,7 +1190,19 @@ void gibbs_sweeps_kernel(const KernelParams p)
         }
         // (the pointer came back from LDS as a generic one: say that it is global, or the store would be a flat_store)
         if (out_base) ((__attribute__((address_space(1))) double*)out_base)[d - p.draw_off] = val;
-        sum_acc += round5(val);
+        const double r5 = round5(val);
+        sum_acc += r5;
+        if constexpr (SIG) {
+            if (p.sample_summary) {
+                smp_acc += r5;
+                const int smp = sw / p.per_sample;
+                if (sw + 1 == (smp + 1) * p.per_sample) {       // the sample's last sweep: its row is complete
+                    const int orole = (c.packed >> 20) & 63;
+                    p.sample_summary[((size_t)w * p.n_samples + smp) * NS + orole] = p.nrun_s > 0 ? smp_acc / (double)p.nrun_s : __builtin_nan("");
+                    smp_acc = 0.0;
+                }
+            }
+        }
     };
 
 #ifdef HMCG_STAMPS
@@ -2045,6 +2069,13 @@ void gibbs_sweeps_kernel(const KernelParams p)
             if (p.sumacc) p.sumacc[(size_t)w * NCK + orole] = sum_acc;
             if (p.summary && p.final_launch)
                 p.summary[(size_t)w * NS + orole] = p.nd > 0 ? sum_acc / (double)p.nd : __builtin_nan("");
+            if constexpr (SIG) {
+                // a launch that stops inside a noise sample leaves that sample's running sums in its row (checkpoint)
+                if (p.sample_summary) {
+                    const int smp = p.sweep_end / p.per_sample, kb = p.sweep_end - smp * p.per_sample - p.burnin_s;
+                    if (kb > 0 && kb < p.nrun_s && smp < p.n_samples) p.sample_summary[((size_t)w * p.n_samples + smp) * NS + orole] = smp_acc;
+                }
+            }
         }
     }
     if (p.sumacc) {

@@ -190,7 +190,6 @@ using namespace hmcg_hostutil;
 int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
 const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
 
-constexpr size_t BIG_MAX_DYN_LDS = 144 * 1024;     // leaves room for the kernel's static LDS within 160 KiB
 
 // The variant for (K, longest window, threads per window, path): the fewest steps per thread that cover the
 // window, then the flavour -- `force` (>= 0, diagnostics) or the table's preference for the batch size.
@@ -238,6 +237,7 @@ struct Plan {
     const Variant* v = nullptr;
     const BigVariant* bv = nullptr;
     int bigL = 0;
+    bool rows = false;             // the LDS-resident kernel with the row-split forward filter (gibbs_big.hpp, FWD = 1)
     size_t dyn = 0;
     bool use_sig = false, use_smooth = false;
     bool needs_pif() const { return bv != nullptr && use_smooth; }   // the LDS-resident smoothing kernel streams pif through pif_final
@@ -245,7 +245,8 @@ struct Plan {
     int L() const { return v ? v->L : bigL; }
     int NH() const { return v ? v->NH : 0; }
     // LDS-resident kernel: per-step pdfs handed from the product phase to the replay, [W][L][K][NT] doubles
-    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)K * (size_t)bv->NT : 0; }
+    // (the row-split filter keeps one value per lane and step of its chunk: 8 L steps per lane)
+    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)(rows ? 8 : K) * (size_t)bv->NT : 0; }
     const void* fptr() const { return v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn); }
 };
 
@@ -268,6 +269,7 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     }
     if (cfg->blend_mask < 0 || (cfg->H < 31 && (cfg->blend_mask >> cfg->H) != 0)) { set_err("blend_mask has bits beyond H"); return HMCG_E_BADARG; }
     if (ex && ex->sigvals && ex->nsave_ld < 1) { set_err("sigvals needs nsave_ld >= 1"); return HMCG_E_BADARG; }
+    if (!use_sig && ex && ex->sample_summary) { set_err("sample_summary needs extras.sig_range (without the signal path it is `summary`)"); return HMCG_E_BADARG; }
     if (ex && ex->corr) {
         if (use_sig || n_samples > 1 || cfg->H < 1 || cfg->nrun < 2) {
             set_err("extras.corr: base runs only (no signal path), H >= 1 (the forecast column) and nrun >= 2");
@@ -292,13 +294,22 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     pl.use_sig = use_sig; pl.use_smooth = use_smooth;
     if (cfg->K < 5) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
     if (!pl.v && !use_sig) {                           // large K, or a window too long for the register-resident variants
-        const BigVariant* tab = use_smooth ? g_big_smooth_variants : g_big_variants;
-        const int ntab = use_smooth ? g_n_big_smooth_variants : g_n_big_variants;
-        for (int i = 0; i < ntab; ++i) if (tab[i].K == cfg->K) pl.bv = &tab[i];
+        // HMCG_BIG_FWD=0: the per-lane chunk products everywhere (diagnostics, A/B); default: the row-split filter where built
+        const bool want_rows = !use_smooth && !(getenv("HMCG_BIG_FWD") && atoi(getenv("HMCG_BIG_FWD")) == 0);
+        if (want_rows)
+            for (int i = 0; i < g_n_big_rows_variants; ++i) if (g_big_rows_variants[i].K == cfg->K) { pl.bv = &g_big_rows_variants[i]; pl.rows = true; }
+        if (!pl.bv) {
+            const BigVariant* tab = use_smooth ? g_big_smooth_variants : g_big_variants;
+            const int ntab = use_smooth ? g_n_big_smooth_variants : g_n_big_variants;
+            for (int i = 0; i < ntab; ++i) if (tab[i].K == cfg->K) pl.bv = &tab[i];
+        }
         if (pl.bv) {
             pl.bigL = (maxT + pl.bv->NT - 1) / pl.bv->NT;
             pl.dyn = (size_t)pl.bv->NT * pl.bigL * (8 + 8 + 4 + 1) + 16;
-            if (pl.dyn > BIG_MAX_DYN_LDS || (cfg->threads_per_window != 0 && cfg->threads_per_window != pl.bv->NT)) pl.bv = nullptr;
+            // dynamic + static LDS of the instantiation must fit the CU's 160 KiB
+            hipFuncAttributes fa{};
+            const size_t stat = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pl.bv->fn)) == hipSuccess ? fa.sharedSizeBytes : 48 * 1024;
+            if (pl.dyn + stat > 160 * 1024 || (cfg->threads_per_window != 0 && cfg->threads_per_window != pl.bv->NT)) pl.bv = nullptr;
         }
     }
     if (!pl.v && !pl.bv) {
@@ -333,7 +344,7 @@ hmcg::KernelParams base_params(const hmcg_config* cfg, int W, const double* dY, 
         p.sigvals = dex->sigvals; p.nsave_ld = dex->nsave_ld;
         p.x_init = dex->x_init; p.x_final = dex->x_final; p.pif_final = dex->pif_final; p.xstate = dex->xstate;
         p.sumacc = dex->sumacc; p.window_ids = dex->window_ids;
-        if (use_sig) { p.end_pos = dex->end_pos; p.blend_mask = cfg->blend_mask; }
+        if (use_sig) { p.end_pos = dex->end_pos; p.blend_mask = cfg->blend_mask; p.sample_summary = dex->sample_summary; }
     }
     return p;
 }
@@ -573,6 +584,9 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const size_t o_dsr = (ex && ex->sig_range) ? LD.add(8 * N) : 0, o_dsvr = (ex && ex->save_range) ? LD.add(8 * N) : 0;
     const size_t o_dep = (ex && ex->end_pos) ? LD.add(4 * N) : 0, o_dss = (ex && ex->sigma_signal) ? LD.add(8 * N) : 0;
     const size_t o_dsv = want_sv ? LD.add(8 * N * nsv) : 0;
+    const bool want_ss = ex && ex->sample_summary;
+    const size_t nss = want_ss ? (size_t)n_samples * NS : 0;
+    const size_t o_dss2 = want_ss ? LD.add(8 * N * nss) : 0;
     const size_t o_dmom = want_corr ? LD.add(8 * N * mom_stride) : 0, o_dcorr = want_corr ? LD.add(8 * N * NCC * NCC) : 0;
     const size_t o_dfs = pl.bv ? LD.add(pl.scratch_bytes(n, cfg->K)) : 0;
     // pinned staging: inputs, small outputs, chunk ring, one-off big extras
@@ -587,6 +601,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const size_t o_psr = (ex && ex->sig_range) ? LP.add(8 * N) : 0, o_psvr = (ex && ex->save_range) ? LP.add(8 * N) : 0;
     const size_t o_pep = (ex && ex->end_pos) ? LP.add(4 * N) : 0, o_pss = (ex && ex->sigma_signal) ? LP.add(8 * N) : 0;
     const size_t o_psv = want_sv ? LP.add(8 * N * nsv) : 0;
+    const size_t o_pss2 = want_ss ? LP.add(8 * N * nss) : 0;
     const size_t o_pcorr = want_corr ? LP.add(8 * N * NCC * NCC) : 0;
     if (c.dev.ensure(LD.total) || c.pin.ensure(LP.total)) {
         set_err("workspace allocation failed (%zu B device, %zu B pinned)", LD.total, LP.total);
@@ -616,6 +631,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             if (ex->sumacc) memcpy(PP(double, o_pacc) + (size_t)i * (NS + K), ex->sumacc + g * (NS + K), 8 * (NS + K));
             if (want_sm) memcpy(PP(double, o_psm) + (size_t)i * ld * K, ex->pi_smooth_mean + g * ld * K, 8 * ld * K);
             if (want_fm) memcpy(PP(double, o_pfm) + (size_t)i * ld * K, ex->pi_filter_mean + g * ld * K, 8 * ld * K);
+            if (want_ss) memcpy(PP(double, o_pss2) + (size_t)i * nss, ex->sample_summary + g * nss, 8 * nss);
         }
     }
 #define H2D(doff, poff, bytes) HIP_TRY(hipMemcpyAsync(D + (doff), P + (poff), (bytes), hipMemcpyHostToDevice, s))
@@ -634,6 +650,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (ex->sumacc) H2D(o_dacc, o_pacc, 8 * N * (NS + K)); else HIP_TRY(hipMemsetAsync(D + o_dacc, 0, 8 * N * (NS + K), s));
         if (want_sm) H2D(o_dsm, o_psm, 8 * N * ld * K);
         if (want_fm) H2D(o_dfm, o_pfm, 8 * N * ld * K);
+        if (want_ss) H2D(o_dss2, o_pss2, 8 * N * nss);
     } else {
         HIP_TRY(hipMemsetAsync(D + o_dst, 0, 4 * N, s));
         // the checkpoint blocks live in the recycled arena: a skipped window writes neither, and must not hand the
@@ -648,6 +665,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (want_xf) HIP_TRY(hipMemsetAsync(D + o_dxf, 0, 4 * N * ld, s));
     if (want_pif) HIP_TRY(hipMemsetAsync(D + o_dpif, 0, 8 * N * ld * K, s));
     if (want_sv) HIP_TRY(hipMemsetAsync(D + o_dsv, 0, 8 * N * nsv, s));
+    if (want_ss && !resume_in) HIP_TRY(hipMemsetAsync(D + o_dss2, 0, 8 * N * nss, s));
 
     hmcg_extras dex{};
     dex.struct_size = (int32_t)sizeof(hmcg_extras);
@@ -663,6 +681,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (ex && ex->end_pos) dex.end_pos = DP(int32_t, o_dep);
     if (ex && ex->sigma_signal) dex.sigma_signal = DP(double, o_dss);
     if (want_sv) { dex.sigvals = DP(double, o_dsv); dex.nsave_ld = ex->nsave_ld; }
+    if (want_ss) dex.sample_summary = DP(double, o_dss2);
 
     hmcg::KernelParams base = base_params(cfg, n, DP(double, o_dY), DP(int32_t, o_dT), (h.yreal && H) ? DP(double, o_dyr) : nullptr,
                                           DP(int32_t, o_dst), &dex, pl.use_sig);
@@ -761,6 +780,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
     if (want_fm) D2H(o_pfm, o_dfm, 8 * N * ld * K);
     if (want_sv) D2H(o_psv, o_dsv, 8 * N * nsv);
+    if (want_ss) D2H(o_pss2, o_dss2, 8 * N * nss);
     if (want_corr) D2H(o_pcorr, o_dcorr, 8 * N * NCC * NCC);
     if (ex && ex->xstate) D2H(o_pxs, o_dxs, N * ld);
     if (ex && ex->sumacc) D2H(o_pacc, o_dacc, 8 * N * (NS + K));
@@ -782,6 +802,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (want_sm) memcpy(ex->pi_smooth_mean + g * ld * K, PP(double, o_psm) + (size_t)i * ld * K, 8 * ld * K);
         if (want_fm) memcpy(ex->pi_filter_mean + g * ld * K, PP(double, o_pfm) + (size_t)i * ld * K, 8 * ld * K);
         if (want_sv) memcpy(ex->sigvals + g * nsv, PP(double, o_psv) + (size_t)i * nsv, 8 * nsv);
+        if (want_ss) memcpy(ex->sample_summary + g * nss, PP(double, o_pss2) + (size_t)i * nss, 8 * nss);
         if (want_corr) memcpy(ex->corr + g * NCC * NCC, PP(double, o_pcorr) + (size_t)i * NCC * NCC, 8 * NCC * NCC);
         if (ex && ex->xstate) memcpy(ex->xstate + g * ld, PP(uint8_t, o_pxs) + (size_t)i * ld, ld);
         if (ex && ex->sumacc) memcpy(ex->sumacc + g * (NS + K), PP(double, o_pacc) + (size_t)i * (NS + K), 8 * (NS + K));

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 104
+#define HMCG_VERSION 105
 #define HMCG_MAXH 8
 #define HMCG_MAXTAIL 32         /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
@@ -139,8 +139,9 @@ typedef struct hmcg_extras {
                                    horizons[k] = h - sigLen, or set blend_mask for h == sigLen */
     double* pi_smooth_mean;     /* [W][ldY][K] optional: mean over the kept draws of the SMOOTHED probabilities
                                    P(X_t | Y_1:T, theta) in sorted labels = the draw-average of the reference's
-                                   samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  K <= 4 variants;
-                                   costs about 20 % more per sweep.  NULL: only pib[end,:] is produced */
+                                   samples.pib[:, t, :] (backwardupdate_P!, src/Hmc.jl:442-457, sorted :513).  Every K and every
+                                   supported T (the LDS-resident kernel needs extras.pif_final on the device entry); about
+                                   half as many draws per second as without.  NULL: only pib[end,:] is produced */
     double* pi_filter_mean;     /* [W][ldY][K] optional: the same draw average for the FILTERED probabilities pif[t,:] in
                                    sorted labels (what the reference's older API returned as "pib" and averaged per date in
                                    data/output/official_insample/forecats_insample.csv, columns s1..s3).  Runs on the same
@@ -154,6 +155,13 @@ typedef struct hmcg_extras {
                                    with H >= 1; the host entries accept NULL for them and then keep the draws on the device),
                                    n_samples <= 1 and the whole run in one call (no sweep_base / sweep_count / RESUME).  A
                                    constant column gives NaN, as Statistics.cor does */
+    double* sample_summary;     /* [W][n_samples][3K+K*K+2H] optional, signal path: for every noise sample the mean over its
+                                   nrun kept draws of the 5-digit-rounded outputs, columns as in `summary` -- one row of the
+                                   `*_summary.csv` files upstream's runaggregate (src/Hmc.jl:1025-1057, grouped by date and
+                                   signalid) makes out of a signal run's per-draw files, taken on the device instead (the
+                                   n_samples * nrun draws need not leave it).  While a sample is incomplete (a call that
+                                   stops inside it: sweep_count) its row holds the raw running sums; a RESUME call reads
+                                   them back from the same buffer */
 } hmcg_extras;
 #define HMCG_CORR_COLUMNS(K) (3 * (K) + (K) * (K) + 1)
 

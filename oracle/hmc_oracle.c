@@ -682,6 +682,27 @@ int hmco_estimate_batch(const double *Y, int ldY, const int *T, int W, int K, in
     return rc;
 }
 
+/* runaggregate over a signal run (src/Hmc.jl:1053-1075: group the 5-digit-rounded per-draw rows by (date, signalid),
+ * mean): from the Julia-layout draw arrays of hmco_estimate_window_ex (nd = n_samples * nrun, sample-major) to
+ * out[n_samples][3K + K^2 + 2H], columns mu | sig2 | pi_end | A(:) column-major | forecasts, draws added in order. */
+void hmco_sample_summary(const double *mu, const double *sig2, const double *A, const double *pi_end, const double *fcast,
+                         int K, int H, int n_samples, int nrun, double *out)
+{
+    const int NS = 3 * K + K * K + 2 * H;
+    const size_t nd = (size_t)n_samples * (size_t)nrun;
+    for (int smp = 0; smp < n_samples; ++smp)
+        for (int c = 0; c < NS; ++c) {
+            const double *col = c < K ? mu + (size_t)c * nd
+                              : c < 2 * K ? sig2 + (size_t)(c - K) * nd
+                              : c < 3 * K ? pi_end + (size_t)(c - 2 * K) * nd
+                              : c < 3 * K + K * K ? A + (size_t)(c - 3 * K) * nd
+                              : fcast + (size_t)(c - 3 * K - K * K) * nd;
+            double acc = 0.0;
+            for (int d = 0; d < nrun; ++d) acc += round5(col[(size_t)smp * nrun + d]);
+            out[(size_t)smp * NS + c] = nrun > 0 ? acc / nrun : NAN;
+        }
+}
+
 /* ---- single-kernel entry points for teacher-forced parity tests ---------- */
 
 /* forward filter only: given theta, returns unsorted pif [T][K]. */

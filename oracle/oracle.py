@@ -45,6 +45,7 @@ def lib():
         L.hmco_normal.restype = C.c_double
         L.hmco_uniform_x.restype = C.c_double
         L.hmco_max_threads.restype = C.c_int
+        L.hmco_sample_summary.restype = None
         _LIB = L
     return _LIB
 
@@ -122,6 +123,10 @@ def estimate_signals(Y, K, burnin, nrun, n_samples=1, sig=(0, 0), kappa=1.0, alp
         raise ValueError("hmco_estimate_window_ex rc=%d" % rc)
     out = dict(mu=mu.T.copy(), sig2=sig2.T.copy(), A=A.transpose(2, 1, 0).copy(), pi_end=pe.T.copy(),
                fcast=fc.T.copy(), summary=summ, sigvals=sv[:, :nsave], x_final=xf, pif_final=pf, status=st.value)
+    # runaggregate's (date, signalid) rows of this run (src/Hmc.jl:1053-1075): per noise sample, means of the rounded draws
+    ss = np.empty((n_samples, 3 * K + K * K + 2 * H))
+    lib().hmco_sample_summary(_p(mu), _p(sig2), _p(A), _p(pe), _p(fc), C.c_int(K), C.c_int(H), C.c_int(n_samples), C.c_int(nrun), _p(ss))
+    out["sample_summary"] = ss
     if want_filter_mean:
         out["pi_filter_mean"] = fm               # (T, K) sorted labels, mean over the kept draws
     if want_smooth:

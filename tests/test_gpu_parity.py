@@ -96,7 +96,7 @@ def test_cfg4_shape_8_states_T5000(hmclib, oracle):
 def check_signals_against_oracle(oracle, Y, Tw, K, burnin, nrun, n_samples, sig, save, kappa, alpha, nu, ssig, yreal):
     W = Y.shape[0]
     g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), yreal, want_state=True, sig_range=sig, save_range=save,
-                                 sigma_signal=ssig, kappa=kappa, n_samples=n_samples, alpha=alpha, nu=nu)
+                                 sigma_signal=ssig, kappa=kappa, n_samples=n_samples, alpha=alpha, nu=nu, want_sample_summary=True)
     for w in range(W):
         o = oracle.estimate_signals(Y[w, :Tw[w]], K, burnin, nrun, n_samples, sig=tuple(sig[w]), kappa=kappa, alpha=alpha,
                                     nu=nu, sigma_signal=float(ssig[w]), save=tuple(save[w]), yreal=yreal[w], window_id=w)
@@ -108,6 +108,7 @@ def check_signals_against_oracle(oracle, Y, Tw, K, burnin, nrun, n_samples, sig,
         ns = save[w][1] - save[w][0]
         assert close(g["sigvals"][w][:, :ns], o["sigvals"]) < TOL
         assert close(g["pif_final"][w, :Tw[w]], o["pif_final"]) < TOL
+        assert close(g["sample_summary"][w], o["sample_summary"]) < TOL          # runaggregate's (date, signalid) rows
     return g
 
 
@@ -321,6 +322,25 @@ def test_checkpoint_resume_is_exact(hmclib):
     assert np.array_equal(b["A"][..., 3:], one["A"][..., 3:])
     assert np.array_equal(b["summary"], one["summary"])
     assert np.array_equal(b["xstate"][:, :700], one["x_final"].astype(np.uint8))
+
+
+def test_signal_run_resumed_inside_a_noise_sample(hmclib):
+    """extras.sample_summary across a checkpoint: 3 noise samples of 4 + 9 sweeps; the first call stops after 19 sweeps
+    (sample 1, two of its kept draws done), the RESUME call finishes.  The per-sample rows of the pair must equal the
+    single call's: the row of an unfinished sample carries its raw running sums from one call to the next."""
+    K, T, W = 3, 400, 4
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    sig = np.stack([Tw - 25, Tw], axis=1).astype(np.int32)
+    kw = dict(sig_range=sig, save_range=sig, sigma_signal=np.array([0.4, 0.9, 0.1, 0.6]), kappa=0.6, n_samples=3, alpha=2.0, nu=2.0,
+              want_sample_summary=True)
+    one = _lib.estimate_batch_host(Y, Tw, K, 4, 9, (12,), fut[:, 11:12], want_state=True, **kw)
+    a = _lib.estimate_batch_host(Y, Tw, K, 4, 9, (12,), fut[:, 11:12], want_state=True, sweep_count=19, **kw)
+    assert np.array_equal(a["sample_summary"][:, 0], one["sample_summary"][:, 0])                # sample 0 complete
+    b = _lib.estimate_batch_host(Y, Tw, K, 4, 9, (12,), fut[:, 11:12], resume_state=a, sweep_base=19,
+                                 resume_sample_summary=a["sample_summary"], **kw)
+    assert np.array_equal(b["sample_summary"], one["sample_summary"]) and np.array_equal(b["summary"], one["summary"])
+    # and the rows average to the whole-run summary (equal sample sizes)
+    assert np.max(np.abs(one["sample_summary"].mean(axis=1) - one["summary"])) < 1e-12
 
 
 def test_threads_per_window_variants_agree(hmclib, oracle):

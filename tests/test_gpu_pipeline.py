@@ -42,7 +42,8 @@ def test_chunked_signal_and_smooth_paths(hmclib, monkeypatch):
     K, T = 3, 500
     Y, Tw, fut = synth.generate_panel(3, T, K)
     sig = np.stack([Tw - 30, Tw], axis=1).astype(np.int32)
-    kw = dict(sig_range=sig, save_range=sig, sigma_signal=np.array([0.4, 0.9, 0.1]), kappa=0.6, n_samples=4, alpha=2.0, nu=2.0)
+    kw = dict(sig_range=sig, save_range=sig, sigma_signal=np.array([0.4, 0.9, 0.1]), kappa=0.6, n_samples=4, alpha=2.0, nu=2.0,
+              want_sample_summary=True)
     monkeypatch.setenv("HMCG_NO_CHUNKS", "1")
     a = _lib.estimate_batch_host(Y, Tw, K, 5, 21, (12,), fut[:, 11:12], want_state=True, **kw)
     b = _lib.estimate_batch_host(Y, Tw, K, 5, 21, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
@@ -53,7 +54,7 @@ def test_chunked_signal_and_smooth_paths(hmclib, monkeypatch):
         a2 = _lib.estimate_batch_host(Y, Tw, K, 5, 21, (12,), fut[:, 11:12], want_state=True, **kw)
         b2 = _lib.estimate_batch_host(Y, Tw, K, 5, 21, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
         assert cap is None or (a2["launches"] > 1 and b2["launches"] > 1)
-        same(a, a2, KEYS + ("sigvals",))
+        same(a, a2, KEYS + ("sigvals", "sample_summary"))
         same(b, b2, KEYS + ("pi_smooth_mean", "pi_filter_mean"))
 
 

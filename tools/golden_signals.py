@@ -1,6 +1,9 @@
 """The signal Monte-Carlo path against every row of the reference's committed
-data/output/signals_official_noise_{0.1,0.3,0.6}_allsignal/forecasts_dispersion.csv (tests/golden/signals_noise_*):
-all end dates in one GPU call per noise level, 100 noise samples each.  Exploratory twin of tests/test_gpu_golden.py."""
+data/output/signals_official_noise_{0.1,0.3,0.6}_allsignal/{forecasts,filtered_means,filtered_variances,filtered_state_probs,
+filtered_trans_probs}_dispersion.csv (tests/golden/signals_noise_*) and against the per-signalid rows of forecasts_summary.csv
+(condensed per date by tools/make_signal_summary_fixture.py): all end dates in one GPU call per noise level, 100 noise samples
+each; the per-sample rows come from extras.sample_summary (the device-side runaggregate), so no draw leaves the GPU.
+Exploratory twin of tests/test_gpu_golden.py."""
 import csv
 import os
 import sys
@@ -27,6 +30,23 @@ def load_dispersion(noise):
     return out
 
 
+FILES = ("filtered_means", "filtered_variances", "filtered_state_probs", "filtered_trans_probs")
+
+
+def load_dispersion_file(noise, var):
+    """date -> {column: value} for one of the filtered_* dispersion files (plain 100-sample rows only)"""
+    out = {}
+    for r in csv.DictReader(open(os.path.join(GOLDEN, "signals_noise_%s_allsignal_%s_dispersion.csv" % (noise, var)))):
+        out.setdefault(r["date"], []).append({k: float(v) for k, v in r.items() if k != "date"})
+    return out
+
+
+def load_summary_stats(noise):
+    """date -> per-date statistics of the reference's forecasts_summary.csv rows (tools/make_signal_summary_fixture.py)"""
+    path = os.path.join(GOLDEN, "signals_noise_%s_allsignal_forecasts_summary_stats.csv" % noise)
+    return {r["date"]: {k: float(v) for k, v in r.items() if k != "date"} for r in csv.DictReader(open(path))}
+
+
 def signal_run(noise, ns=100, burnin=1000, nrun=2000):
     y, dates = load_inflation()
     fx = load_dispersion(noise)
@@ -42,15 +62,59 @@ def signal_run(noise, ns=100, burnin=1000, nrun=2000):
         ssig[i] = 0.5 * (fx[d][0]["signal_1_std"] + fx[d][0]["signal_2_std"])
         sig[i] = (0, e); save[i] = (e - 2, e)
     t0 = time.perf_counter()
-    r = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), yreal, want_draws=("fcast",), sig_range=sig, save_range=save,
-                                 sigma_signal=ssig, kappa=float(noise), n_samples=ns, alpha=2.0, nu=2.0)
+    r = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), yreal, want_draws=False, sig_range=sig, save_range=save,
+                                 sigma_signal=ssig, kappa=float(noise), n_samples=ns, alpha=2.0, nu=2.0, want_sample_summary=True)
     wall = time.perf_counter() - t0
-    f = r["fcast"][:, 0, :].reshape(W, ns, nrun).mean(axis=2)           # per-sample mean forecast = one row of forecasts_summary.csv
-    e_ = r["fcast"][:, 1, :].reshape(W, ns, nrun).mean(axis=2)
+    ss = r["sample_summary"]                                             # (W, ns, 3K+K^2+2): the rows of upstream's *_summary.csv
+    f = ss[:, :, 3 * K + K * K]                                          # per-sample mean forecast = one row of forecasts_summary.csv
+    e_ = ss[:, :, 3 * K + K * K + 1]
     sv = r["sigvals"]                                                    # (W, ns, 2)
     return dict(dates=use, f_mean=f.mean(axis=1), f_std=f.std(axis=1, ddof=1), e_mean=e_.mean(axis=1), sv_mean=sv.mean(axis=1),
                 sv_std=sv.std(axis=1, ddof=1), ssig=ssig, status=r["status"], wall=wall, kernel_ms=r["kernel_ms"], fx=fx, ns=ns,
-                skipped=[d for d in fx if d not in use])
+                skipped=[d for d in fx if d not in use], ss=ss, sv=sv, noise=noise, K=K)
+
+
+def compare_filtered(run):
+    """For each of the four filtered_* dispersion files: standardised difference of the across-sample mean of every column
+    (z, under "both are means of ns independent per-sample rows") and the ratio of the across-sample standard deviations."""
+    K, ns, ss = run["K"], run["ns"], run["ss"]
+    cols = {"filtered_means": (slice(0, K), ["state_%d" % (i + 1) for i in range(K)]),
+            "filtered_variances": (slice(K, 2 * K), ["state_%d" % (i + 1) for i in range(K)]),
+            "filtered_state_probs": (slice(2 * K, 3 * K), ["state_%d" % (i + 1) for i in range(K)]),
+            # data columns are column-major A(:); the committed header is the legacy naming trans_<j>_<i> (SURVEY 8c (3)): positional
+            "filtered_trans_probs": (slice(3 * K, 3 * K + K * K), ["trans_%d_%d" % (j + 1, i + 1) for j in range(K) for i in range(K)])}
+    out = {}
+    for var, (sl, names) in cols.items():
+        fx = load_dispersion_file(run["noise"], var)
+        ref_m = np.array([[fx[d][0][n + "_mean"] for n in names] for d in run["dates"]])
+        ref_s = np.array([[fx[d][0][n + "_std"] for n in names] for d in run["dates"]])
+        ours = ss[:, :, sl]
+        m, sd = ours.mean(axis=1), ours.std(axis=1, ddof=1)
+        se = np.sqrt(sd ** 2 + ref_s ** 2) / np.sqrt(ns)
+        out[var] = dict(z=(m - ref_m) / np.maximum(se, 1e-300), diff=m - ref_m, ratio=sd / np.maximum(ref_s, 1e-300), ref_m=ref_m, ref_s=ref_s, m=m, sd=sd)
+    return out
+
+
+def compare_summary_rows(run):
+    """The per-signalid rows of forecasts_summary.csv, in distribution: per date the quartiles of the per-sample mean forecast
+    across the noise samples and the least-squares slope of the per-sample forecast on the sample's last noisy signal
+    (how a noise sample's forecast moves with the signal it was shown)."""
+    st = load_summary_stats(run["noise"])
+    f = run["ss"][:, :, 3 * run["K"] + run["K"] ** 2]
+    s2 = run["sv"][:, :, 1]
+    q = np.quantile(f, [0.25, 0.5, 0.75], axis=1).T
+    ref = lambda k: np.array([st[d][k] for d in run["dates"]])
+    sd_ref = ref("f_std")
+    # standard error of a sample quantile of n draws from a near-normal law: sd * sqrt(p(1-p)/n) / phi(z_p)
+    se_q = lambda p, sd: sd * np.sqrt(p * (1 - p) / run["ns"]) / {0.25: 0.31778, 0.5: 0.39894, 0.75: 0.31778}[p]
+    zq = {p: (q[:, i] - ref(k)) / (np.sqrt(2.0) * se_q(p, 0.5 * (sd_ref + f.std(axis=1, ddof=1))))
+          for i, (p, k) in enumerate(((0.25, "f_q25"), (0.5, "f_q50"), (0.75, "f_q75")))}
+    fc = f - f.mean(axis=1, keepdims=True); sc = s2 - s2.mean(axis=1, keepdims=True)
+    slope = (fc * sc).sum(axis=1) / (sc * sc).sum(axis=1)
+    resid = fc - slope[:, None] * sc
+    se_slope = np.sqrt((resid ** 2).sum(axis=1) / (run["ns"] - 2) / (sc * sc).sum(axis=1))
+    z_slope = (slope - ref("slope_s2")) / np.sqrt(se_slope ** 2 + ref("slope_s2_se") ** 2)
+    return dict(zq=zq, slope=slope, slope_ref=ref("slope_s2"), z_slope=z_slope)
 
 
 def compare(run):
@@ -66,8 +130,10 @@ def compare(run):
 
 
 if __name__ == "__main__":
-    for noise in (sys.argv[1:] or ["0.1", "0.3", "0.6"]):
-        run = signal_run(noise)
+    # usage: golden_signals.py [noise ...] [burnin=N] [nrun=N]
+    kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+    for noise in ([a for a in sys.argv[1:] if "=" not in a] or ["0.1", "0.3", "0.6"]):
+        run = signal_run(noise, **kw)
         c = compare(run)
         q = lambda v: np.round(np.quantile(v, [0.01, 0.25, 0.5, 0.75, 0.99]), 3)
         print("noise %s: %d dates (%d fixture rows skipped: %s), %.1f s wall, kernel %.1f s, flagged %d" % (
@@ -76,3 +142,14 @@ if __name__ == "__main__":
               " mean z %.3f  rms z %.3f" % (c["z_mean"].mean(), np.sqrt((c["z_mean"] ** 2).mean())))
         print("   max |diff| %.4f; std ratio quantiles" % np.abs(c["diff"]).max(), q(c["ratio"]), "geo-mean %.3f" % np.exp(np.log(c["ratio"]).mean()))
         print("   z(signal means) rms %.3f %.3f" % (np.sqrt((c["zs1"] ** 2).mean()), np.sqrt((c["zs2"] ** 2).mean())))
+        for var, r in compare_filtered(run).items():
+            az = np.abs(r["z"])
+            print("   %-22s |z| median %.2f  q99 %.2f  max %.2f | mean z per column %s | std ratio median per column %s" % (
+                var, np.median(az), np.quantile(az, 0.99), az.max(), np.round(r["z"].mean(axis=0), 2), np.round(np.median(r["ratio"], axis=0), 2)))
+        try:
+            cs = compare_summary_rows(run)
+            print("   forecasts_summary rows: quartile z rms", {p: round(float(np.sqrt((z ** 2).mean())), 3) for p, z in cs["zq"].items()},
+                  "| slope on signal_2: ours median %.4f ref median %.4f, z rms %.3f mean %.3f" % (
+                      np.median(cs["slope"]), np.median(cs["slope_ref"]), np.sqrt((cs["z_slope"] ** 2).mean()), cs["z_slope"].mean()))
+        except FileNotFoundError as e:
+            print("   (no summary-stats fixture: %s)" % e)
