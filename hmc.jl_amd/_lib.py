@@ -155,7 +155,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
                         end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None, want_corr=False,
-                        want_sample_summary=False, resume_sample_summary=None):
+                        want_sample_summary=False, resume_sample_summary=None, nan_fill=True):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,).
@@ -266,7 +266,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     # a skipped window (non-finite data, bad T, bad ranges) was not computed: its outputs read NaN, never a
     # plausible-looking zero (the reference would have thrown, src/Hmc.jl:435)
     skipped = (out["status"] & ST_SKIPPED) != 0
-    if skipped.any():
+    if skipped.any() and nan_fill:
         for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final", "corr", "sample_summary"):
             if name in out:
                 out[name][skipped] = np.nan

@@ -30,15 +30,9 @@ struct ThetaBufBig {
     double pi_end[K];
 };
 
-// FWD = 1 (row-split forward filter, below): the chunk products, the chunks' prefix vectors and a per-wave exchange slot
-template <int K, int NT, int FWD = 0>
+template <int K, int NT>
 struct BigShared {
     static constexpr int NW = NT / 64;
-    static constexpr int NCH = NT / 8;                 // chunks per window in the row-split filter (8 lanes per chunk)
-    static constexpr int STG = 8 * 10;                 // doubles per exchange buffer: 8 groups x (8 values + 2 of padding: no bank conflicts)
-    double cp[FWD ? NCH : 1][FWD ? K * K : 1];         // chunk products, row-major
-    double vin[FWD ? NCH + 1 : 1][8];                  // prefix vector of every chunk (rho' P_0 ... P_{c-1}, rescaled)
-    double stage[FWD ? NW : 1][2][STG];                // 8-value exchange within a lane group, double-buffered
     static constexpr int KK = K * K;
     static constexpr int NG = K + KK;
     unsigned cnt[NW][KK];         // per-wave transition histograms C_ij (field i*K+j)
@@ -121,25 +115,16 @@ __device__ __forceinline__ void count_le_sorted_batch(const double (&c)[K][K], c
     for (int s = 0; s < K; ++s) idx[s] = (b1[s] ? 4 : 0) + (b2[s] ? 2 : 0) + ((m3[s] <= thr[s]) ? 1 : 0);
 }
 
-// FWD selects the forward filter (src/Hmc.jl:371-440) between Bb and Bd:
-//   0  every lane owns L consecutive steps: K x K chunk product per lane, matrix scan over lanes, per-lane replay;
-//   1  ROW-SPLIT: 8 lanes own 8 L consecutive steps.  Row r of a product Q M_t needs row r of Q only, so lane r of the
-//      group carries ONE row (8 doubles instead of 64: the whole of A fits in registers beside it, no AGPR traffic, one
-//      pdf per lane and step, shared through an LDS slot); the NT/8 chunk products go to LDS and the chunks' prefix
-//      vectors follow by plain vector-matrix steps; in the replay lane s of the group carries column s: its running
-//      sums over r of pif[t-1,r] A[r,s] are the cumulative weights of X[t-1] | X[t] = s, as in the per-lane replay.
-// Same results (the association order of the products differs: floats agree to ~1e-14, states exactly).
-template <int K, int NT, bool SM = false, int FWD = 0>
+template <int K, int NT, bool SM = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
-    static_assert(FWD == 0 || !SM, "the smoothing pass rides on the per-lane chunk products");
     static_assert(K >= 2 && K <= 8, "4-bit map entries: K <= 8 (K <= 4 normally runs on the register-resident kernel; this one\n"
                                     "also serves small K when the window is too long for it)");
     constexpr int NW = NT / 64;
     constexpr int KK = K * K;
     constexpr int NG = K + KK;
     static_assert(NW >= 2, "needs shadow waves");
-    using Sh = BigShared<K, NT, FWD>;
+    using Sh = BigShared<K, NT>;
     __shared__ Sh sh;
     extern __shared__ double dyn_lds[];
     const int cap = NT * L;
@@ -148,7 +133,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     uint32_t* const maps = reinterpret_cast<uint32_t*>(dyn_lds + 2 * (size_t)cap);   // [cap] state maps g_t
     uint8_t* const xs = reinterpret_cast<uint8_t*>(maps + cap);     // [cap + 8] states
     // HBM scratch of this thread's per-step pdfs, [L][K] with the thread index fastest (p.fscr is [W][L][K][NT])
-    double* const fscr = p.fscr + (size_t)blockIdx.x * L * (FWD ? 8 : K) * NT + threadIdx.x;
+    double* const fscr = p.fscr + (size_t)blockIdx.x * L * K * NT + threadIdx.x;
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -615,495 +600,297 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         STAMP(1);
         __syncthreads();                                                     // Bb
         STAMP(2);
-        if constexpr (FWD == 1) {
-            // ---- row-split forward filter ----
-            constexpr int GS = 8;
-            const int Lc = GS * L;                                   // steps per chunk
-            const int grp = tid / GS, r = tid & (GS - 1);            // chunk; row (products) / column (replay) of this lane
-            const bool rv = r < K;
-            const int tc0 = grp * Lc;
-            double* const stg = &sh.stage[wave][0][(lane / GS) * 10];
-            constexpr int STG = Sh::STG;
-            const bool kept_sweep = sweep >= p.burnin_s;
-            (void)kept_sweep;
-            // max / or over the 8 lanes of a group (quad_perm xor 1, xor 2, then the half-row mirror)
-            auto g8_max = [&](unsigned v) __attribute__((always_inline)) -> unsigned {
-                v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false));
-                v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false));
-                return max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, false));
-            };
-            auto g8_or = [&](unsigned v) __attribute__((always_inline)) -> unsigned {
-                v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false);
-                v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false);
-                return v | (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, false);
-            };
-            auto g8_rescale = [&](double (&v)[K]) __attribute__((always_inline)) {
-                unsigned m = (unsigned)__double2hiint(v[0]);
+        // ---- forward filter: local product of this thread's L matrices A diag(f_t) ----
+        double Q[KK];
 #pragma unroll
-                for (int i = 1; i < K; ++i) m = max(m, (unsigned)__double2hiint(v[i]));
-                m = g8_max(m);
-                const int be = (int)(m >> 20);
-                int e = (be > 0 && be < 2040) ? 1022 - be : 0;
-                asm volatile("" : "+v"(e));
+        for (int r = 0; r < K; ++r)
 #pragma unroll
-                for (int i = 0; i < K; ++i) v[i] = ldexp(v[i], e);
-            };
-            {
-                // -- chunk products: row r of  prod_t A diag(f_t)  over the chunk's 8 L steps
-                const double mu_r = th.mu[rv ? r : 0], isd_r = th.isd[rv ? r : 0], coef_r = th.coef[rv ? r : 0];
-                double a[K][K];
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-#pragma unroll
-                    for (int ss = 0; ss < K; ++ss) a[k][ss] = th.A[k][ss];
-                double q[K];
-#pragma unroll
-                for (int ss = 0; ss < K; ++ss) q[ss] = (ss == r) ? 1.0 : 0.0;
-                // this lane's pdf of step j, scaled by the power of two that brings the step's largest pdf into [0.5,1)
-                auto emis = [&](int j) __attribute__((always_inline)) -> double {
-                    const double z = (ylds[tc0 + j] - mu_r) * isd_r;
-                    double f = exp_tab(-(z * z), sh.exptab) * coef_r;
-                    const unsigned hm = g8_max(rv ? (unsigned)__double2hiint(f) : 0u);
-                    f = ldexp(f, 1022 - (int)(hm >> 20));
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hm < 0x01A56E1Fu) != 0ull, 0)) {      // rare, wave-uniform branch
-                        if (hm < 0x01A56E1Fu) {
-                            if (tc0 + j < T) st |= HMCG_ST_EMIS_UNDERFLOW;
-                            f = 1.0;
-                        }
+            for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
+        double N[KK];
+        const bool kept_sweep = sweep >= p.burnin_s;              // one sample per launch on this path
+        const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr);
+        {
+            // Q <- Q * (A diag(f_t)), in place, four rows at a time: row r of the product needs row r of Q only, so once a
+            // block of rows has all its columns it replaces the block it came from -- one matrix and half a matrix live
+            // (192 registers) instead of two (256, i.e. ~190 VGPR<->AGPR copies per step).  One column of A at a time from
+            // LDS (wave-uniform address: a broadcast read), the block's rows against it; every column is read once per block
+            // (twice per step for K = 8: 64 broadcast reads instead of 32, far from loading the LDS pipe -- a two-rows form
+            // that read A four times per step had been LDS-bound).
+            constexpr int RB = 4;
+            for (int l = 0; l < L; ++l) {
+                asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
+                if constexpr (SM) {
+                    if (t0 + l >= T) {               // padded steps stay out of the products (identity): the suffix scan
+#pragma unroll                                       //  of the smoothing pass must not see them
+                        for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = 1.0;
+                        continue;
                     }
-                    return rv ? f : 0.0;
-                };
-                double fme = emis(0);
-                for (int j = 0; j < Lc; ++j) {
-                    fscr[(size_t)j * NT] = fme;                       // the replay's lane (same lane) reads it back: [j][thread]
-                    stg[(j & 1) * STG + r] = fme;
-                    __builtin_amdgcn_wave_barrier();
-                    double fv[K];
-#pragma unroll
-                    for (int ss = 0; ss < K; ++ss) fv[ss] = stg[(j & 1) * STG + ss];
-                    const double fnx = emis(j + 1 < Lc ? j + 1 : j);  // next step's pdf while the exchange is in flight
-                    double nq[K];
-#pragma unroll
-                    for (int ss = 0; ss < K; ++ss) {
-                        double acc = q[0] * a[0][ss];
-#pragma unroll
-                        for (int k = 1; k < K; ++k) acc = fma(q[k], a[k][ss], acc);
-                        nq[ss] = acc * fv[ss];
-                    }
-#pragma unroll
-                    for (int ss = 0; ss < K; ++ss) q[ss] = nq[ss];
-                    if ((j & 7) == 7) g8_rescale(q);
-                    fme = fnx;
                 }
-                g8_rescale(q);
-                if (rv) {
+                double fv[K];
+                pdfs(th, ylds[t0 + l], t0 + l < T, fv);
+                // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
+                // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
 #pragma unroll
-                    for (int ss = 0; ss < K; ++ss) sh.cp[grp][r * K + ss] = q[ss];
-                }
-            }
-            STAMP(4);
-            __syncthreads();                                                 // Bc: every chunk product is in LDS
-            STAMP(6);
-            {
-                // -- prefix vectors v_c = rho' P_0 ... P_{c-1}: lane s of every group computes entry s of v_{c+1} = v_c P_c, the
-                //    8 entries meet in LDS.  Every wave runs the chain as far as its own last chunk (identical values, so the
-                //    waves' writes to sh.vin agree) -- no barrier between this and the replay.
-                const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-                const int clast = (wave_u + 1) * (64 / GS) - 1;              // this wave's last chunk
-                double v[8];
+                for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = k < K ? th.rho[k] : 0.0;
-                if (lane < 8) sh.vin[0][lane] = lane < K ? th.rho[lane < K ? lane : 0] : 0.0;
-                double pc[K];
+                for (int r0 = 0; r0 < K; r0 += RB) {
+                    double tb[RB][K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) pc[k] = sh.cp[0][k * K + (rv ? r : 0)];
-                for (int c = 0; c < clast; ++c) {
-                    double pn[K];                                            // column r of the next chunk product, ahead of its use
+                    for (int s = 0; s < K; ++s) {
+                        double a[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) pn[k] = sh.cp[c + 1][k * K + (rv ? r : 0)];
-                    double acc0 = v[0] * pc[0], acc1 = K > 1 ? v[1] * pc[K > 1 ? 1 : 0] : 0.0;
+                        for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
 #pragma unroll
-                    for (int k = 2; k < K; k += 2) {
-                        acc0 = fma(v[k], pc[k], acc0);
-                        if (k + 1 < K) acc1 = fma(v[k + 1], pc[k + 1 < K ? k + 1 : 0], acc1);
-                    }
-                    double nv = rv ? acc0 + acc1 : 0.0;
-                    {
-                        const unsigned m = g8_max((unsigned)__double2hiint(nv));
-                        const int be = (int)(m >> 20);
-                        int e = (be > 0 && be < 2040) ? 1022 - be : 0;
-                        nv = ldexp(nv, e);
-                    }
-                    if (lane < 8) sh.vin[c + 1][lane] = nv;
-                    __builtin_amdgcn_wave_barrier();
+                        for (int rr = 0; rr < RB; ++rr) {
+                            if (r0 + rr < K) {
+                                double acc = Q[(r0 + rr) * K] * a[0];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = sh.vin[c + 1][k];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) pc[k] = pn[k];
-                }
-            }
-            STAMP(5);
-            {
-                // -- replay (:413-432) fused with the state maps of update_X (:459-484), lane s = column s of the group's chunk:
-                //    cum[r] = sum_{r' <= r} pif[t-1,r'] A[r',s] are the cumulative weights of X[t-1] | X[t] = s, cum[K-1] f_s is
-                //    pif[t,s] before normalisation.  pif travels unnormalised (exact power-of-two rescaling now and then): the
-                //    draw compares cum[r] with u cum[K-1], the eps() guard pif[t,s] > eps() with eps() times the step's total.
-                const bool want_pif = last_sweep && p.pif_final != nullptr;
-                double pv[K], acol[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) { pv[k] = sh.vin[grp][k]; acol[k] = rv ? Atp[(rv ? r : 0) * K + k] : 0.0; }
-                double fcur = fscr[0];
-                double ucur = uxs[tc0 >= 1 ? tc0 - 1 : 0];
-                for (int j = 0; j < Lc; ++j) {
-                    const int t = tc0 + j;
-                    const double fnx = fscr[(size_t)(j + 1 < Lc ? j + 1 : j) * NT];
-                    const double unx = uxs[t];                                   // the next step's uniform (t + 1 - 1)
-                    double cum[K];
-                    cum[0] = pv[0] * acol[0];
-#pragma unroll
-                    for (int rr = 1; rr < K; ++rr) cum[rr] = fma(pv[rr], acol[rr], cum[rr - 1]);
-                    const double ctot = cum[K - 1];
-                    double nv = ctot * fcur;
-                    stg[(j & 1) * STG + r] = nv;
-                    __builtin_amdgcn_wave_barrier();
-                    const int idx = count_le_sorted<K - 1>(cum, ucur * ctot);
-                    double pn[K], total = 0.0;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) { pn[k] = stg[(j & 1) * STG + k]; total += pn[k]; }
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(total > 0.0)) != 0ull, 0)) {
-                        if (!(total > 0.0)) {
-                            if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
-#pragma unroll
-                            for (int k = 0; k < K; ++k) pn[k] = 1.0 / K;
-                            nv = 1.0 / K;
-                            total = 1.0;
-                        }
-                    }
-                    int idx_uni = 0;
-                    if constexpr ((K & (K - 1)) == 0) {
-                        idx_uni = (int)(ucur * (double)K);
-                    } else {
-                        double cp = 0.0;
-#pragma unroll
-                        for (int rr = 0; rr < K - 1; ++rr) { cp += 1.0 / K; idx_uni += (cp <= ucur) ? 1 : 0; }
-                    }
-                    const bool okg = nv > EPS64 * total;                         // pif[t,s] > eps() (:472)
-                    const unsigned mine = rv ? (unsigned)(okg ? idx : idx_uni) << (4 * r) : 0u;
-                    const unsigned m = g8_or(mine);
-                    if (t >= 1) maps[t - 1] = m;                                 // (the group's lanes agree on address and value)
-                    if (t == T - 1) {
-                        if (rv) th.pi_end[r] = nv * rcp_fast(total);
-                        sh.ulast = uxs[T - 1];
-                    }
-                    if (want_pif) {
-                        if (t < T && rv) p.pif_final[((size_t)w * p.ldY + t) * K + r] = nv * rcp_fast(total);
-                    }
-                    if ((j & 3) == 3) {
-                        const int be = (int)((unsigned)__double2hiint(total) >> 20);
-                        int e = (be > 0 && be < 2040) ? 1022 - be : 0;
-                        asm volatile("" : "+v"(e));
-#pragma unroll
-                        for (int k = 0; k < K; ++k) pv[k] = ldexp(pn[k], e);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) pv[k] = pn[k];
-                    }
-                    fcur = fnx; ucur = unx;
-                }
-            }
-        } else {
-            // ---- forward filter: local product of this thread's L matrices A diag(f_t) ----
-            double Q[KK];
-    #pragma unroll
-            for (int r = 0; r < K; ++r)
-    #pragma unroll
-                for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
-            double N[KK];
-            const bool kept_sweep = sweep >= p.burnin_s;              // one sample per launch on this path
-            const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr);
-            {
-                // Q <- Q * (A diag(f_t)), in place, four rows at a time: row r of the product needs row r of Q only, so once a
-                // block of rows has all its columns it replaces the block it came from -- one matrix and half a matrix live
-                // (192 registers) instead of two (256, i.e. ~190 VGPR<->AGPR copies per step).  One column of A at a time from
-                // LDS (wave-uniform address: a broadcast read), the block's rows against it; every column is read once per block
-                // (twice per step for K = 8: 64 broadcast reads instead of 32, far from loading the LDS pipe -- a two-rows form
-                // that read A four times per step had been LDS-bound).
-                constexpr int RB = 4;
-                for (int l = 0; l < L; ++l) {
-                    asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
-                    if constexpr (SM) {
-                        if (t0 + l >= T) {               // padded steps stay out of the products (identity): the suffix scan
-    #pragma unroll                                       //  of the smoothing pass must not see them
-                            for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = 1.0;
-                            continue;
-                        }
-                    }
-                    double fv[K];
-                    pdfs(th, ylds[t0 + l], t0 + l < T, fv);
-                    // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
-                    // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
-    #pragma unroll
-                    for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
-    #pragma unroll
-                    for (int r0 = 0; r0 < K; r0 += RB) {
-                        double tb[RB][K];
-    #pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            double a[K];
-    #pragma unroll
-                            for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
-    #pragma unroll
-                            for (int rr = 0; rr < RB; ++rr) {
-                                if (r0 + rr < K) {
-                                    double acc = Q[(r0 + rr) * K] * a[0];
-    #pragma unroll
-                                    for (int k = 1; k < K; ++k) acc = fma(Q[(r0 + rr) * K + k], a[k], acc);
-                                    tb[rr][s] = acc * fv[s];
-                                }
+                                for (int k = 1; k < K; ++k) acc = fma(Q[(r0 + rr) * K + k], a[k], acc);
+                                tb[rr][s] = acc * fv[s];
                             }
                         }
-    #pragma unroll
-                        for (int rr = 0; rr < RB; ++rr)
-    #pragma unroll
-                            for (int s = 0; s < K; ++s) if (r0 + rr < K) Q[(r0 + rr) * K + s] = tb[rr][s];
                     }
-                    // (every step's largest pdf lies in [0.5,1): eight steps between two exact power-of-two rescalings are far
-                    //  inside the fp64 range)
-                    if ((l & 7) == 7) rescale_pow2<KK>(Q);
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+                        for (int s = 0; s < K; ++s) if (r0 + rr < K) Q[(r0 + rr) * K + s] = tb[rr][s];
                 }
-                rescale_pow2<KK>(Q);
+                // (every step's largest pdf lies in [0.5,1): eight steps between two exact power-of-two rescalings are far
+                //  inside the fp64 range)
+                if ((l & 7) == 7) rescale_pow2<KK>(Q);
             }
-            double Qloc[SM ? KK : 1];                                 // this thread's own chunk product, for the suffix scan
-            if constexpr (SM) {
-    #pragma unroll
-                for (int i = 0; i < KK; ++i) Qloc[i] = Q[i];
+            rescale_pow2<KK>(Q);
+        }
+        double Qloc[SM ? KK : 1];                                 // this thread's own chunk product, for the suffix scan
+        if constexpr (SM) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i) Qloc[i] = Q[i];
+        }
+        (void)Qloc;
+        STAMP(4);
+        scan_level_rowwise<K, DPP_ROW_SHR1, 0xF>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(N, Q);
+        rescale_pow2<KK>(Q);
+        scan_level_rowwise<K, DPP_ROW_SHR4, 0xF>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_SHR8, 0xF>(N, Q);
+        rescale_pow2<KK>(Q);
+        scan_level_rowwise<K, DPP_ROW_BCAST15, 0xA>(Q, N);
+        scan_level_rowwise<K, DPP_ROW_BCAST31, 0xC>(N, Q);
+        rescale_pow2<KK>(Q);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i) sh.wtot[wave][i] = Q[i];
+        }
+        STAMP(5);
+        __syncthreads();                                                     // Bc
+        STAMP(6);
+        // prefix vector rho' * (earlier waves) * (exclusive lane prefix)
+        double av[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) av[s] = th.rho[s];
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        for (int ww = 0; ww < wave_u; ++ww) {
+            double nv[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double acc = av[0] * sh.wtot[ww][s];
+#pragma unroll
+                for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
+                nv[s] = acc;
             }
-            (void)Qloc;
-            STAMP(4);
-            scan_level_rowwise<K, DPP_ROW_SHR1, 0xF>(Q, N);
-            scan_level_rowwise<K, DPP_ROW_SHR2, 0xF>(N, Q);
-            rescale_pow2<KK>(Q);
-            scan_level_rowwise<K, DPP_ROW_SHR4, 0xF>(Q, N);
-            scan_level_rowwise<K, DPP_ROW_SHR8, 0xF>(N, Q);
-            rescale_pow2<KK>(Q);
-            scan_level_rowwise<K, DPP_ROW_BCAST15, 0xA>(Q, N);
-            scan_level_rowwise<K, DPP_ROW_BCAST31, 0xC>(N, Q);
-            rescale_pow2<KK>(Q);
-            if (lane == 63) {
-    #pragma unroll
-                for (int i = 0; i < KK; ++i) sh.wtot[wave][i] = Q[i];
+#pragma unroll
+            for (int s = 0; s < K; ++s) av[s] = nv[s];
+        }
+        {
+            double nv[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < K; ++r)
+                    acc = fma(av[r], dpp_f64<DPP_WAVE_SHR1, 0xF>((r == s) ? 1.0 : 0.0, Q[r * K + s]), acc);
+                nv[s] = acc;
             }
-            STAMP(5);
-            __syncthreads();                                                     // Bc
-            STAMP(6);
-            // prefix vector rho' * (earlier waves) * (exclusive lane prefix)
-            double av[K];
-    #pragma unroll
-            for (int s = 0; s < K; ++s) av[s] = th.rho[s];
-            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-            for (int ww = 0; ww < wave_u; ++ww) {
-                double nv[K];
-    #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    double acc = av[0] * sh.wtot[ww][s];
-    #pragma unroll
-                    for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
-                    nv[s] = acc;
+            rescale_pow2<K>(nv);
+#pragma unroll
+            for (int s = 0; s < K; ++s) av[s] = nv[s];
+        }
+        // ---- replay of the normalised recursion (:413-432), fused with the state maps of update_X (:459-484):
+        // at step t the running sums over r of pif[t-1,r] A[r,s] are both pif[t,s]/f and the cumulative
+        // weights of the draw X[t-1] | X[t] = s; the eps() guard is pif[t,s] itself.
+        // (The pdfs come back from the scratch the product phase filled; the transition matrix stays in LDS, a column at a
+        //  time -- 64 more live doubles were measured to land in AGPRs and cost four times the instructions of the reads.)
+        {
+            const bool want_pif = (last_sweep || do_smooth) && p.pif_final != nullptr;
+            double fnext[K];                     // pdfs of the step ahead, on their way from the scratch
+#pragma unroll
+            for (int s = 0; s < K; ++s) fnext[s] = fscr[(size_t)s * NT];
+            constexpr int NRES = 2;              // the first columns of A stay in registers: the step's first chains need not wait for LDS
+            double a_first[NRES][K];
+#pragma unroll
+            for (int s = 0; s < NRES; ++s)
+#pragma unroll
+                for (int k = 0; k < K; ++k) a_first[s][k] = Atp[s * K + k];
+            for (int l = 0; l < L; ++l) {
+                asm volatile("" ::: "memory");       // as above: (the rest of) A stays in LDS
+                const int t = t0 + l;
+                const double u = uxs[t >= 1 ? t - 1 : 0];
+                double fv[K];
+#pragma unroll
+                for (int s = 0; s < K; ++s) fv[s] = fnext[s];
+                if (l + 1 < L) {
+#pragma unroll
+                    for (int s = 0; s < K; ++s) fnext[s] = fscr[((size_t)(l + 1) * K + s) * NT];
                 }
-    #pragma unroll
-                for (int s = 0; s < K; ++s) av[s] = nv[s];
-            }
-            {
-                double nv[K];
-    #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    double acc = 0.0;
-    #pragma unroll
-                    for (int r = 0; r < K; ++r)
-                        acc = fma(av[r], dpp_f64<DPP_WAVE_SHR1, 0xF>((r == s) ? 1.0 : 0.0, Q[r * K + s]), acc);
-                    nv[s] = acc;
-                }
-                rescale_pow2<K>(nv);
-    #pragma unroll
-                for (int s = 0; s < K; ++s) av[s] = nv[s];
-            }
-            // ---- replay of the normalised recursion (:413-432), fused with the state maps of update_X (:459-484):
-            // at step t the running sums over r of pif[t-1,r] A[r,s] are both pif[t,s]/f and the cumulative
-            // weights of the draw X[t-1] | X[t] = s; the eps() guard is pif[t,s] itself.
-            // (The pdfs come back from the scratch the product phase filled; the transition matrix stays in LDS, a column at a
-            //  time -- 64 more live doubles were measured to land in AGPRs and cost four times the instructions of the reads.)
-            {
-                const bool want_pif = (last_sweep || do_smooth) && p.pif_final != nullptr;
-                double fnext[K];                     // pdfs of the step ahead, on their way from the scratch
-    #pragma unroll
-                for (int s = 0; s < K; ++s) fnext[s] = fscr[(size_t)s * NT];
-                constexpr int NRES = 2;              // the first columns of A stay in registers: the step's first chains need not wait for LDS
-                double a_first[NRES][K];
-    #pragma unroll
-                for (int s = 0; s < NRES; ++s)
-    #pragma unroll
-                    for (int k = 0; k < K; ++k) a_first[s][k] = Atp[s * K + k];
-                for (int l = 0; l < L; ++l) {
-                    asm volatile("" ::: "memory");       // as above: (the rest of) A stays in LDS
-                    const int t = t0 + l;
-                    const double u = uxs[t >= 1 ? t - 1 : 0];
-                    double fv[K];
-    #pragma unroll
-                    for (int s = 0; s < K; ++s) fv[s] = fnext[s];
-                    if (l + 1 < L) {
-    #pragma unroll
-                        for (int s = 0; s < K; ++s) fnext[s] = fscr[((size_t)(l + 1) * K + s) * NT];
-                    }
-                    double nv[K], total = 0.0;
-                    uint32_t mok = 0;
-                    {
-                        // the K cumulative-sum chains first, then the K categorical draws level by level (count_le_sorted_batch):
-                        // one search after another is a chain of compare -> select -> compare through VCC, K of them in a row
-                        double cum[K][K], thr[K];
-    #pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            double a[K];
-    #pragma unroll
-                            for (int k = 0; k < K; ++k) a[k] = s < NRES ? a_first[s < NRES ? s : 0][k] : Atp[s * K + k];
-                            double acc = av[0] * a[0];
-                            cum[s][0] = acc;
-    #pragma unroll
-                            for (int r = 1; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[s][r] = acc; }
-                            thr[s] = u * acc;
-                            nv[s] = acc * fv[s];
-                            total += nv[s];
-                        }
-                        int idx[K];
-                        count_le_sorted_batch<K>(cum, thr, idx);
-    #pragma unroll
-                        for (int s = 0; s < K; ++s) mok |= (uint32_t)idx[s] << (4 * s);
-                    }
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(total > 0.0)) != 0ull, 0)) {
-                        if (!(total > 0.0)) {
-                            if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
-    #pragma unroll
-                            for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
-                            total = 1.0;
-                        }
-                    }
-                    const double inv = rcp_fast(total);
-                    int idx_uni = 0;
-                    if constexpr ((K & (K - 1)) == 0) {
-                        idx_uni = (int)(u * (double)K);         // K a power of two: the cumulative j/K are exact, #{j/K <= u} = floor(K u), u < 1
-                    } else {
-                        double cp = 0.0;
-    #pragma unroll
-                        for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx_uni += (cp <= u) ? 1 : 0; }
-                    }
-                    // guards (:472-480): the entries whose pif[t,s] fails eps() take the uniform draw -- built as a nibble
-                    // mask so that the common case (no failure in the wave) costs one select per state
-                    uint32_t fail = 0;
-    #pragma unroll
+                double nv[K], total = 0.0;
+                uint32_t mok = 0;
+                {
+                    // the K cumulative-sum chains first, then the K categorical draws level by level (count_le_sorted_batch):
+                    // one search after another is a chain of compare -> select -> compare through VCC, K of them in a row
+                    double cum[K][K], thr[K];
+#pragma unroll
                     for (int s = 0; s < K; ++s) {
-                        av[s] = nv[s] * inv;                                        // pif[t,s]
-                        fail |= (av[s] > EPS64) ? 0u : (0xFu << (4 * s));
+                        double a[K];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) a[k] = s < NRES ? a_first[s < NRES ? s : 0][k] : Atp[s * K + k];
+                        double acc = av[0] * a[0];
+                        cum[s][0] = acc;
+#pragma unroll
+                        for (int r = 1; r < K; ++r) { acc = fma(av[r], a[r], acc); cum[s][r] = acc; }
+                        thr[s] = u * acc;
+                        nv[s] = acc * fv[s];
+                        total += nv[s];
                     }
-                    const uint32_t m = (mok & ~fail) | ((uint32_t)idx_uni * 0x11111111u & fail);
-                    if (t >= 1) maps[t - 1] = m;                                     // g_{t-1}; entries at/after T-1 are overridden below
-                    if (t == T - 1) {
-    #pragma unroll
-                        for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
-                        sh.ulast = uxs[T - 1];
+                    int idx[K];
+                    count_le_sorted_batch<K>(cum, thr, idx);
+#pragma unroll
+                    for (int s = 0; s < K; ++s) mok |= (uint32_t)idx[s] << (4 * s);
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(total > 0.0)) != 0ull, 0)) {
+                    if (!(total > 0.0)) {
+                        if (t < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) nv[s] = 1.0 / K;
+                        total = 1.0;
                     }
-                    if (want_pif) {
-                        if (t < T) {
-    #pragma unroll
-                            for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t) * K + s] = av[s];
-                        }
+                }
+                const double inv = rcp_fast(total);
+                int idx_uni = 0;
+                if constexpr ((K & (K - 1)) == 0) {
+                    idx_uni = (int)(u * (double)K);         // K a power of two: the cumulative j/K are exact, #{j/K <= u} = floor(K u), u < 1
+                } else {
+                    double cp = 0.0;
+#pragma unroll
+                    for (int r = 0; r < K - 1; ++r) { cp += 1.0 / K; idx_uni += (cp <= u) ? 1 : 0; }
+                }
+                // guards (:472-480): the entries whose pif[t,s] fails eps() take the uniform draw -- built as a nibble
+                // mask so that the common case (no failure in the wave) costs one select per state
+                uint32_t fail = 0;
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    av[s] = nv[s] * inv;                                        // pif[t,s]
+                    fail |= (av[s] > EPS64) ? 0u : (0xFu << (4 * s));
+                }
+                const uint32_t m = (mok & ~fail) | ((uint32_t)idx_uni * 0x11111111u & fail);
+                if (t >= 1) maps[t - 1] = m;                                     // g_{t-1}; entries at/after T-1 are overridden below
+                if (t == T - 1) {
+#pragma unroll
+                    for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
+                    sh.ulast = uxs[T - 1];
+                }
+                if (want_pif) {
+                    if (t < T) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) p.pif_final[((size_t)w * p.ldY + t) * K + s] = av[s];
                     }
                 }
             }
-            if constexpr (SM) {
-                if (do_smooth) {
-                    // ---- backwardupdate_P! as the beta recursion b_{t-1} = A (f_t o b_t), b_{T-1} = 1; pib[t,:] ~ pif[t,:] o b_t.
-                    // b at the end of a thread's chunk = (product of the LATER chunks' matrices) * 1: within the wave an
-                    // exclusive suffix scan of the chunk products (prefix scan on lane-reversed data, multiplication order
-                    // flipped), then the later waves' totals -- the forward wave totals, already in LDS.
-                    double bw[K];
-    #pragma unroll
-                    for (int r = 0; r < K; ++r) bw[r] = 1.0;
-                    for (int ww = NW - 1; ww > wave_u; --ww) {
-                        double nb[K];
-    #pragma unroll
+        }
+        if constexpr (SM) {
+            if (do_smooth) {
+                // ---- backwardupdate_P! as the beta recursion b_{t-1} = A (f_t o b_t), b_{T-1} = 1; pib[t,:] ~ pif[t,:] o b_t.
+                // b at the end of a thread's chunk = (product of the LATER chunks' matrices) * 1: within the wave an
+                // exclusive suffix scan of the chunk products (prefix scan on lane-reversed data, multiplication order
+                // flipped), then the later waves' totals -- the forward wave totals, already in LDS.
+                double bw[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) bw[r] = 1.0;
+                for (int ww = NW - 1; ww > wave_u; --ww) {
+                    double nb[K];
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c < K; ++c) acc = fma(sh.wtot[ww][r * K + c], bw[c], acc);
+                        nb[r] = acc;
+                    }
+                    rescale_pow2<K>(nb);
+#pragma unroll
+                    for (int r = 0; r < K; ++r) bw[r] = nb[r];
+                }
+                // lane-reversed copy, inclusive scan with the own matrix on the LEFT (column-wise DPP fetch of the source)
+                double R[KK], R2[KK];
+#pragma unroll
+                for (int i = 0; i < KK; ++i) R[i] = __shfl(Qloc[i], 63 - lane, 64);
+                scan_level_colwise<K, DPP_ROW_SHR1, 0xF>(R, R2);
+                scan_level_colwise<K, DPP_ROW_SHR2, 0xF>(R2, R);
+                rescale_pow2<KK>(R);
+                scan_level_colwise<K, DPP_ROW_SHR4, 0xF>(R, R2);
+                scan_level_colwise<K, DPP_ROW_SHR8, 0xF>(R2, R);
+                rescale_pow2<KK>(R);
+                scan_level_colwise<K, DPP_ROW_BCAST15, 0xA>(R, R2);
+                scan_level_colwise<K, DPP_ROW_BCAST31, 0xC>(R2, R);
+                rescale_pow2<KK>(R);
+                // exclusive suffix of lane j = inclusive result held by reversed lane (63-j)-1, i.e. physical lane 62-j
+                double b[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) {
+                        const double e = __shfl(R[r * K + c], lane < 63 ? 62 - lane : 0, 64);
+                        acc = fma((lane < 63) ? e : ((r == c) ? 1.0 : 0.0), bw[c], acc);
+                    }
+                    b[r] = acc;
+                }
+                rescale_pow2<K>(b);
+                double mu_s[K];
+                int order[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) mu_s[i] = th.mu[i];
+                sort_order<K>(mu_s, order);
+                for (int l = L - 1; l >= 0; --l) {
+                    asm volatile("" ::: "memory");
+                    const int t = t0 + l;
+                    if (t < T) {
+                        double g[K], pfv[K], tot = 0.0;
+                        const double* pft = p.pif_final + ((size_t)w * p.ldY + t) * K;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) { pfv[s] = pft[s]; g[s] = pfv[s] * b[s]; tot += g[s]; }
+                        const double inv = rcp_fast(tot);
+#pragma unroll
+                        for (int q = 0; q < K; ++q) {
+                            double gq = 0.0, fq = 0.0;
+#pragma unroll
+                            for (int s = 0; s < K; ++s) { gq = (order[q] == s) ? g[s] : gq; fq = (order[q] == s) ? pfv[s] : fq; }
+                            if (p.pi_smooth_mean) p.pi_smooth_mean[((size_t)w * p.ldY + t) * K + q] += gq * inv;   // sorted labels (:513)
+                            if (p.pi_filter_mean) p.pi_filter_mean[((size_t)w * p.ldY + t) * K + q] += fq;         // sorted pif[t,:] (:512)
+                        }
+                        double fv[K], fb[K], nb[K];
+#pragma unroll
+                        for (int s = 0; s < K; ++s) fv[s] = fscr[((size_t)l * K + s) * NT];    // this step's pdfs, from the product phase
+#pragma unroll
+                        for (int s = 0; s < K; ++s) fb[s] = fv[s] * b[s];
+#pragma unroll
                         for (int r = 0; r < K; ++r) {
                             double acc = 0.0;
-    #pragma unroll
-                            for (int c = 0; c < K; ++c) acc = fma(sh.wtot[ww][r * K + c], bw[c], acc);
+#pragma unroll
+                            for (int s = 0; s < K; ++s) acc = fma(th.A[r][s], fb[s], acc);
                             nb[r] = acc;
                         }
                         rescale_pow2<K>(nb);
-    #pragma unroll
-                        for (int r = 0; r < K; ++r) bw[r] = nb[r];
-                    }
-                    // lane-reversed copy, inclusive scan with the own matrix on the LEFT (column-wise DPP fetch of the source)
-                    double R[KK], R2[KK];
-    #pragma unroll
-                    for (int i = 0; i < KK; ++i) R[i] = __shfl(Qloc[i], 63 - lane, 64);
-                    scan_level_colwise<K, DPP_ROW_SHR1, 0xF>(R, R2);
-                    scan_level_colwise<K, DPP_ROW_SHR2, 0xF>(R2, R);
-                    rescale_pow2<KK>(R);
-                    scan_level_colwise<K, DPP_ROW_SHR4, 0xF>(R, R2);
-                    scan_level_colwise<K, DPP_ROW_SHR8, 0xF>(R2, R);
-                    rescale_pow2<KK>(R);
-                    scan_level_colwise<K, DPP_ROW_BCAST15, 0xA>(R, R2);
-                    scan_level_colwise<K, DPP_ROW_BCAST31, 0xC>(R2, R);
-                    rescale_pow2<KK>(R);
-                    // exclusive suffix of lane j = inclusive result held by reversed lane (63-j)-1, i.e. physical lane 62-j
-                    double b[K];
-    #pragma unroll
-                    for (int r = 0; r < K; ++r) {
-                        double acc = 0.0;
-    #pragma unroll
-                        for (int c = 0; c < K; ++c) {
-                            const double e = __shfl(R[r * K + c], lane < 63 ? 62 - lane : 0, 64);
-                            acc = fma((lane < 63) ? e : ((r == c) ? 1.0 : 0.0), bw[c], acc);
-                        }
-                        b[r] = acc;
-                    }
-                    rescale_pow2<K>(b);
-                    double mu_s[K];
-                    int order[K];
-    #pragma unroll
-                    for (int i = 0; i < K; ++i) mu_s[i] = th.mu[i];
-                    sort_order<K>(mu_s, order);
-                    for (int l = L - 1; l >= 0; --l) {
-                        asm volatile("" ::: "memory");
-                        const int t = t0 + l;
-                        if (t < T) {
-                            double g[K], pfv[K], tot = 0.0;
-                            const double* pft = p.pif_final + ((size_t)w * p.ldY + t) * K;
-    #pragma unroll
-                            for (int s = 0; s < K; ++s) { pfv[s] = pft[s]; g[s] = pfv[s] * b[s]; tot += g[s]; }
-                            const double inv = rcp_fast(tot);
-    #pragma unroll
-                            for (int q = 0; q < K; ++q) {
-                                double gq = 0.0, fq = 0.0;
-    #pragma unroll
-                                for (int s = 0; s < K; ++s) { gq = (order[q] == s) ? g[s] : gq; fq = (order[q] == s) ? pfv[s] : fq; }
-                                if (p.pi_smooth_mean) p.pi_smooth_mean[((size_t)w * p.ldY + t) * K + q] += gq * inv;   // sorted labels (:513)
-                                if (p.pi_filter_mean) p.pi_filter_mean[((size_t)w * p.ldY + t) * K + q] += fq;         // sorted pif[t,:] (:512)
-                            }
-                            double fv[K], fb[K], nb[K];
-    #pragma unroll
-                            for (int s = 0; s < K; ++s) fv[s] = fscr[((size_t)l * K + s) * NT];    // this step's pdfs, from the product phase
-    #pragma unroll
-                            for (int s = 0; s < K; ++s) fb[s] = fv[s] * b[s];
-    #pragma unroll
-                            for (int r = 0; r < K; ++r) {
-                                double acc = 0.0;
-    #pragma unroll
-                                for (int s = 0; s < K; ++s) acc = fma(th.A[r][s], fb[s], acc);
-                                nb[r] = acc;
-                            }
-                            rescale_pow2<K>(nb);
-    #pragma unroll
-                            for (int r = 0; r < K; ++r) b[r] = nb[r];
-                        }
+#pragma unroll
+                        for (int r = 0; r < K; ++r) b[r] = nb[r];
                     }
                 }
             }

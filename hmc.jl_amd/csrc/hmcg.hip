@@ -237,7 +237,6 @@ struct Plan {
     const Variant* v = nullptr;
     const BigVariant* bv = nullptr;
     int bigL = 0;
-    bool rows = false;             // the LDS-resident kernel with the row-split forward filter (gibbs_big.hpp, FWD = 1)
     size_t dyn = 0;
     bool use_sig = false, use_smooth = false;
     bool needs_pif() const { return bv != nullptr && use_smooth; }   // the LDS-resident smoothing kernel streams pif through pif_final
@@ -245,8 +244,7 @@ struct Plan {
     int L() const { return v ? v->L : bigL; }
     int NH() const { return v ? v->NH : 0; }
     // LDS-resident kernel: per-step pdfs handed from the product phase to the replay, [W][L][K][NT] doubles
-    // (the row-split filter keeps one value per lane and step of its chunk: 8 L steps per lane)
-    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)(rows ? 8 : K) * (size_t)bv->NT : 0; }
+    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)K * (size_t)bv->NT : 0; }
     const void* fptr() const { return v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn); }
 };
 
@@ -294,15 +292,9 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     pl.use_sig = use_sig; pl.use_smooth = use_smooth;
     if (cfg->K < 5) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
     if (!pl.v && !use_sig) {                           // large K, or a window too long for the register-resident variants
-        // HMCG_BIG_FWD=0: the per-lane chunk products everywhere (diagnostics, A/B); default: the row-split filter where built
-        const bool want_rows = !use_smooth && !(getenv("HMCG_BIG_FWD") && atoi(getenv("HMCG_BIG_FWD")) == 0);
-        if (want_rows)
-            for (int i = 0; i < g_n_big_rows_variants; ++i) if (g_big_rows_variants[i].K == cfg->K) { pl.bv = &g_big_rows_variants[i]; pl.rows = true; }
-        if (!pl.bv) {
-            const BigVariant* tab = use_smooth ? g_big_smooth_variants : g_big_variants;
-            const int ntab = use_smooth ? g_n_big_smooth_variants : g_n_big_variants;
-            for (int i = 0; i < ntab; ++i) if (tab[i].K == cfg->K) pl.bv = &tab[i];
-        }
+        const BigVariant* tab = use_smooth ? g_big_smooth_variants : g_big_variants;
+        const int ntab = use_smooth ? g_n_big_smooth_variants : g_n_big_variants;
+        for (int i = 0; i < ntab; ++i) if (tab[i].K == cfg->K) pl.bv = &tab[i];
         if (pl.bv) {
             pl.bigL = (maxT + pl.bv->NT - 1) / pl.bv->NT;
             pl.dyn = (size_t)pl.bv->NT * pl.bigL * (8 + 8 + 4 + 1) + 16;
@@ -514,6 +506,12 @@ struct HostArrays {
 int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx, int n, const HostArrays& h, hmcg_timing* timing)
 {
     const auto t_call = std::chrono::steady_clock::now();
+    // HMCG_TRACE=1 (diagnostics): host-side timeline of the call on stderr -- where the wall time beyond the kernels goes
+    static const bool trace_on = getenv("HMCG_TRACE") != nullptr;
+    std::vector<std::pair<const char*, double>> trace;
+    auto mark = [&](const char* what) {
+        if (trace_on) trace.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+    };
     // HMCG_FAIL_DEVICE=id (diagnostics): the host entry fails on that device id before it touches anything -- lets a test
     // see hmcg_estimate_batch_multi report one worker's error while the others complete
     if (const char* fe = getenv("HMCG_FAIL_DEVICE")) {
@@ -563,43 +561,57 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const bool chunked = chunks.size() > 1;
 
     // ---- layouts ----
+    // Both arenas open with the same INPUT block (Y, T, ids, yreal, the optional per-window inputs: same order, same sizes), so
+    // one H2D carries it; the device arena follows with the blocks a fresh (non-resumed) call needs zeroed, contiguous, so one
+    // memset clears them; status and summary sit next to each other on both sides, so one D2H brings them back.  (Every
+    // separate copy or memset is a node on the stream ahead of the first kernel: ten of them cost more than the 2 MB of Y.)
     Layout LD, LP;
-    const size_t o_dY = LD.add(8 * N * ld), o_dT = LD.add(4 * N), o_dst = LD.add(4 * N), o_dwid = LD.add(4 * N);
-    const size_t o_dyr = (h.yreal && H) ? LD.add(8 * N * H) : 0;
-    const size_t o_dsum = h.summary ? LD.add(8 * N * NS) : 0;
-    const size_t chunk_bytes = 8 * ncols * N * (size_t)chunk_max;
-    size_t o_dchunk[RING] = {}, o_pchunk[RING] = {};
-    const int nring = stream_draws ? (int)std::min<size_t>(RING, chunks.size()) : 0;
-    for (int r = 0; r < nring; ++r) o_dchunk[r] = LD.add(chunk_bytes);
     const bool need_ckpt = chunked || resume_in || (ex && (ex->xstate || ex->sumacc)) || se < total_sweeps;
-    const size_t o_dxs = need_ckpt ? LD.add(N * ld) : 0, o_dacc = need_ckpt ? LD.add(8 * N * (NS + K)) : 0;
     const bool want_xi = ex && ex->x_init, want_xf = ex && ex->x_final;
     const bool user_pif = ex && ex->pif_final, want_pif = user_pif || pl.needs_pif();     // scratch of the smoothing kernel
     const bool want_sm = ex && ex->pi_smooth_mean, want_fm = ex && ex->pi_filter_mean;
     const bool want_sv = ex && ex->sigvals && ex->nsave_ld > 0;
     const size_t nsv = want_sv ? (size_t)n_samples * (size_t)ex->nsave_ld : 0;
-    const size_t o_dxi = want_xi ? LD.add(4 * N * ld) : 0, o_dxf = want_xf ? LD.add(4 * N * ld) : 0;
-    const size_t o_dpif = want_pif ? LD.add(8 * N * ld * K) : 0;
-    const size_t o_dsm = want_sm ? LD.add(8 * N * ld * K) : 0, o_dfm = want_fm ? LD.add(8 * N * ld * K) : 0;
-    const size_t o_dsr = (ex && ex->sig_range) ? LD.add(8 * N) : 0, o_dsvr = (ex && ex->save_range) ? LD.add(8 * N) : 0;
-    const size_t o_dep = (ex && ex->end_pos) ? LD.add(4 * N) : 0, o_dss = (ex && ex->sigma_signal) ? LD.add(8 * N) : 0;
-    const size_t o_dsv = want_sv ? LD.add(8 * N * nsv) : 0;
     const bool want_ss = ex && ex->sample_summary;
     const size_t nss = want_ss ? (size_t)n_samples * NS : 0;
+    const bool has_yr = h.yreal && H, has_sr = ex && ex->sig_range, has_svr = ex && ex->save_range, has_ep = ex && ex->end_pos,
+               has_ssg = ex && ex->sigma_signal;
+    size_t o_dY, o_dT, o_dwid, o_dyr = 0, o_dxi = 0, o_dsr = 0, o_dsvr = 0, o_dep = 0, o_dss = 0;
+    size_t o_pY, o_pT, o_pwid, o_pyr = 0, o_pxi = 0, o_psr = 0, o_psvr = 0, o_pep = 0, o_pss = 0;
+    auto both = [&](size_t bytes, size_t& od, size_t& op) { od = LD.add(bytes); op = LP.add(bytes); };
+    both(8 * N * ld, o_dY, o_pY); both(4 * N, o_dT, o_pT); both(4 * N, o_dwid, o_pwid);
+    if (has_yr) both(8 * N * H, o_dyr, o_pyr);
+    if (want_xi) both(4 * N * ld, o_dxi, o_pxi);
+    if (has_sr) both(8 * N, o_dsr, o_psr);
+    if (has_svr) both(8 * N, o_dsvr, o_psvr);
+    if (has_ep) both(4 * N, o_dep, o_pep);
+    if (has_ssg) both(8 * N, o_dss, o_pss);
+    const size_t input_bytes = LD.total;                       // == LP.total: the block [0, input_bytes) of either arena
+    // device: the zeroed block
+    const size_t zero_begin = LD.total;
+    const size_t o_dst = LD.add(4 * N);
+    const size_t o_dsum = h.summary ? LD.add(8 * N * NS) : 0;
+    const size_t o_dxs = need_ckpt ? LD.add(N * ld) : 0, o_dacc = need_ckpt ? LD.add(8 * N * (NS + K)) : 0;
+    const size_t o_dxf = want_xf ? LD.add(4 * N * ld) : 0;
+    const size_t o_dsv = want_sv ? LD.add(8 * N * nsv) : 0;
     const size_t o_dss2 = want_ss ? LD.add(8 * N * nss) : 0;
+    const size_t o_dpif = want_pif ? LD.add(8 * N * ld * K) : 0;
+    const size_t o_dsm = want_sm ? LD.add(8 * N * ld * K) : 0, o_dfm = want_fm ? LD.add(8 * N * ld * K) : 0;
+    const size_t zero_bytes = LD.total - zero_begin;
+    const size_t chunk_bytes = 8 * ncols * N * (size_t)chunk_max;
+    size_t o_dchunk[RING] = {}, o_pchunk[RING] = {};
+    const int nring = stream_draws ? (int)std::min<size_t>(RING, chunks.size()) : 0;
+    for (int r = 0; r < nring; ++r) o_dchunk[r] = LD.add(chunk_bytes);
     const size_t o_dmom = want_corr ? LD.add(8 * N * mom_stride) : 0, o_dcorr = want_corr ? LD.add(8 * N * NCC * NCC) : 0;
     const size_t o_dfs = pl.bv ? LD.add(pl.scratch_bytes(n, cfg->K)) : 0;
-    // pinned staging: inputs, small outputs, chunk ring, one-off big extras
-    const size_t o_pY = LP.add(8 * N * ld), o_pT = LP.add(4 * N), o_pst = LP.add(4 * N), o_pwid = LP.add(4 * N);
-    const size_t o_pyr = (h.yreal && H) ? LP.add(8 * N * H) : 0;
+    // pinned staging beyond the input block: small outputs (status | summary adjacent, as on the device), chunk ring, extras
+    const size_t o_pst = LP.add(4 * N);
     const size_t o_psum = h.summary ? LP.add(8 * N * NS) : 0;
     for (int r = 0; r < nring; ++r) o_pchunk[r] = LP.add(chunk_bytes);
     const size_t o_pxs = need_ckpt ? LP.add(N * ld) : 0, o_pacc = need_ckpt ? LP.add(8 * N * (NS + K)) : 0;
-    const size_t o_pxi = want_xi ? LP.add(4 * N * ld) : 0, o_pxf = want_xf ? LP.add(4 * N * ld) : 0;
+    const size_t o_pxf = want_xf ? LP.add(4 * N * ld) : 0;
     const size_t o_ppif = user_pif ? LP.add(8 * N * ld * K) : 0;
     const size_t o_psm = want_sm ? LP.add(8 * N * ld * K) : 0, o_pfm = want_fm ? LP.add(8 * N * ld * K) : 0;
-    const size_t o_psr = (ex && ex->sig_range) ? LP.add(8 * N) : 0, o_psvr = (ex && ex->save_range) ? LP.add(8 * N) : 0;
-    const size_t o_pep = (ex && ex->end_pos) ? LP.add(4 * N) : 0, o_pss = (ex && ex->sigma_signal) ? LP.add(8 * N) : 0;
     const size_t o_psv = want_sv ? LP.add(8 * N * nsv) : 0;
     const size_t o_pss2 = want_ss ? LP.add(8 * N * nss) : 0;
     const size_t o_pcorr = want_corr ? LP.add(8 * N * NCC * NCC) : 0;
@@ -634,16 +646,9 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             if (want_ss) memcpy(PP(double, o_pss2) + (size_t)i * nss, ex->sample_summary + g * nss, 8 * nss);
         }
     }
+    mark("packed");
 #define H2D(doff, poff, bytes) HIP_TRY(hipMemcpyAsync(D + (doff), P + (poff), (bytes), hipMemcpyHostToDevice, s))
-    H2D(o_dY, o_pY, 8 * N * ld);
-    H2D(o_dT, o_pT, 4 * N);
-    H2D(o_dwid, o_pwid, 4 * N);
-    if (h.yreal && H) H2D(o_dyr, o_pyr, 8 * N * H);
-    if (want_xi) H2D(o_dxi, o_pxi, 4 * N * ld);
-    if (ex && ex->sig_range) H2D(o_dsr, o_psr, 8 * N);
-    if (ex && ex->save_range) H2D(o_dsvr, o_psvr, 8 * N);
-    if (ex && ex->end_pos) H2D(o_dep, o_pep, 4 * N);
-    if (ex && ex->sigma_signal) H2D(o_dss, o_pss, 8 * N);
+    H2D(0, 0, input_bytes);                                    // Y, T, ids, yreal and the optional per-window inputs
     if (resume_in) {
         H2D(o_dst, o_pst, 4 * N);
         H2D(o_dxs, o_pxs, N * ld);
@@ -651,22 +656,18 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         if (want_sm) H2D(o_dsm, o_psm, 8 * N * ld * K);
         if (want_fm) H2D(o_dfm, o_pfm, 8 * N * ld * K);
         if (want_ss) H2D(o_dss2, o_pss2, 8 * N * nss);
+        // outputs a skipped window never writes read as zero
+        if (h.summary) HIP_TRY(hipMemsetAsync(D + o_dsum, 0, 8 * N * NS, s));
+        if (want_xf) HIP_TRY(hipMemsetAsync(D + o_dxf, 0, 4 * N * ld, s));
+        if (want_pif) HIP_TRY(hipMemsetAsync(D + o_dpif, 0, 8 * N * ld * K, s));
+        if (want_sv) HIP_TRY(hipMemsetAsync(D + o_dsv, 0, 8 * N * nsv, s));
     } else {
-        HIP_TRY(hipMemsetAsync(D + o_dst, 0, 4 * N, s));
-        // the checkpoint blocks live in the recycled arena: a skipped window writes neither, and must not hand the
-        // caller an earlier call's bytes
-        if (need_ckpt) { HIP_TRY(hipMemsetAsync(D + o_dxs, 0, N * ld, s)); HIP_TRY(hipMemsetAsync(D + o_dacc, 0, 8 * N * (NS + K), s)); }
-        if (want_sm) HIP_TRY(hipMemsetAsync(D + o_dsm, 0, 8 * N * ld * K, s));
-        if (want_fm) HIP_TRY(hipMemsetAsync(D + o_dfm, 0, 8 * N * ld * K, s));
+        // status, summary, the checkpoint blocks (they live in the recycled arena: a skipped window writes none of them and
+        // must not hand the caller an earlier call's bytes), x_final, sigvals, the per-sample summaries, pif, the running
+        // smoothed / filtered sums: one memset
+        HIP_TRY(hipMemsetAsync(D + zero_begin, 0, zero_bytes, s));
     }
 #undef H2D
-    // outputs a skipped window never writes read as zero
-    if (h.summary) HIP_TRY(hipMemsetAsync(D + o_dsum, 0, 8 * N * NS, s));
-    if (want_xf) HIP_TRY(hipMemsetAsync(D + o_dxf, 0, 4 * N * ld, s));
-    if (want_pif) HIP_TRY(hipMemsetAsync(D + o_dpif, 0, 8 * N * ld * K, s));
-    if (want_sv) HIP_TRY(hipMemsetAsync(D + o_dsv, 0, 8 * N * nsv, s));
-    if (want_ss && !resume_in) HIP_TRY(hipMemsetAsync(D + o_dss2, 0, 8 * N * nss, s));
-
     hmcg_extras dex{};
     dex.struct_size = (int32_t)sizeof(hmcg_extras);
     dex.window_ids = DP(uint32_t, o_dwid);
@@ -696,6 +697,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     // touching the CUs -- a helped sweep kernel leaves no registers for a blit kernel to run beside it).  Kernel
     // c + RING reuses both the device and the pinned buffer of chunk c: the host enqueues it only after it has waited
     // for copy c and scattered chunk c.
+    mark("inputs enqueued");
     const int nch = (int)chunks.size();
     double kernel_ms = 0.0;
     std::vector<hipEvent_t> tev;          // per-chunk timing events (created only when timing is requested)
@@ -722,6 +724,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         };
         if (8 * ncols * N * ndc < ((size_t)1 << 20)) part(0, 1);                  // small chunks: not worth a hand-off
         else c.pool.run(part);
+        mark("scattered");
     };
     int next_scatter = 0;
     for (int cidx = 0; cidx < nch; ++cidx) {
@@ -731,6 +734,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             // free the ring slot: chunk cidx - RING must have left the device buffer and the pinned buffer
             while (next_scatter <= cidx - RING) {
                 HIP_TRY(hipEventSynchronize(c.evc[next_scatter % RING]));
+                mark("copy landed");
                 scatter(next_scatter);
                 ++next_scatter;
             }
@@ -748,8 +752,8 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             p.A = cols[2].ncol ? cb + ndc * cols[2].off * N : nullptr;
             p.pi_end = cols[3].ncol ? cb + ndc * cols[3].off * N : nullptr;
             p.fcast = cols[4].ncol ? cb + ndc * cols[4].off * N : nullptr;
-            // a skipped window writes nothing: its block must read as zero
-            HIP_TRY(hipMemsetAsync(cb, 0, 8 * ncols * N * ndc, s));
+            // (a skipped window writes nothing into its block: its rows of the caller's arrays are zeroed at the end of the
+            //  call, once the status words are back -- no memset node per chunk on the stream)
         }
         if (timing) HIP_TRY(hipEventRecord(tev[(size_t)cidx], s));
         launch_kernel(pl, p, s);
@@ -768,13 +772,13 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             }
         }
     }
+    mark("kernels enqueued");
     if (timing) HIP_TRY(hipEventRecord(tev[(size_t)nch], s));
     if (want_corr) HIP_TRY(hmcg_host::launch_corr_finalize(DP(double, o_dmom), DP(double, o_dcorr), n, cfg->K, s));
 
     // ---- small outputs and one-off extras: D2H on the compute stream (after the last kernel) ----
 #define D2H(poff, doff, bytes) HIP_TRY(hipMemcpyAsync(P + (poff), D + (doff), (bytes), hipMemcpyDeviceToHost, s))
-    D2H(o_pst, o_dst, 4 * N);
-    if (h.summary) D2H(o_psum, o_dsum, 8 * N * NS);
+    D2H(o_pst, o_dst, (h.summary ? o_dsum + 8 * N * NS : o_dst + 4 * N) - o_dst);        // status | summary, adjacent on both sides
     if (want_xf) D2H(o_pxf, o_dxf, 4 * N * ld);
     if (user_pif) D2H(o_ppif, o_dpif, 8 * N * ld * K);
     if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
@@ -789,12 +793,26 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (stream_draws) {
         for (; next_scatter < nch; ++next_scatter) {
             HIP_TRY(hipEventSynchronize(c.evc[next_scatter % RING]));
+            mark("copy landed");
             scatter(next_scatter);
         }
     }
+    mark("chunks scattered");
     HIP_TRY(hipStreamSynchronize(s));
+    mark("stream idle");
+    constexpr int32_t ST_SKIPPED = HMCG_ST_NONFINITE | HMCG_ST_BAD_T | HMCG_ST_BAD_RANGE;
     for (int i = 0; i < n; ++i) {
         const size_t g = row(i);
+        if (PP(int32_t, o_pst)[i] & ST_SKIPPED) {
+            // a skipped window produced nothing: what the scatter copied for it is whatever the chunk buffers held; the
+            // contract (hmcg.h) says its outputs read zero
+            const size_t d0 = (size_t)chunks.front().d0, dn = (size_t)(chunks.back().d1 - chunks.front().d0);
+            if (copy_out && dn > 0)
+                for (const Col& cc : cols)
+                    if (cc.host)
+                        for (size_t q = 0; q < cc.ncol; ++q) memset(cc.host + (size_t)nd_total * (q + cc.ncol * g) + d0, 0, 8 * dn);
+            if (want_corr) memset(PP(double, o_pcorr) + (size_t)i * NCC * NCC, 0, 8 * NCC * NCC);
+        }
         if (h.status) h.status[g] = PP(int32_t, o_pst)[i];
         if (h.summary) memcpy(h.summary + g * NS, PP(double, o_psum) + (size_t)i * NS, 8 * NS);
         if (want_xf) memcpy(ex->x_final + g * ld, PP(int32_t, o_pxf) + (size_t)i * ld, 4 * ld);
@@ -809,6 +827,12 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     }
 #undef DP
 #undef PP
+    mark("small outputs copied");
+    if (trace_on) {
+        fprintf(stderr, "[trace] device %d, %d windows, %d chunks:", c.device, n, nch);
+        for (const auto& t : trace) fprintf(stderr, " %s %.3f |", t.first, t.second);
+        fprintf(stderr, "\n");
+    }
     if (timing) {
         for (int cidx = 0; cidx < nch; ++cidx) {
             float ms = 0.f;

@@ -10,12 +10,6 @@ const BigVariant g_big_variants[] = {
     { 7, 256, hmcg::gibbs_sweeps_kernel_big<7, 256> }, { 8, 256, hmcg::gibbs_sweeps_kernel_big<8, 256> },
 };
 const int g_n_big_variants = (int)(sizeof(g_big_variants) / sizeof(g_big_variants[0]));
-// ... with the row-split forward filter (8 lanes per chunk of 8 L steps, one row / column per lane): K = 5..8
-const BigVariant g_big_rows_variants[] = {
-    { 5, 256, hmcg::gibbs_sweeps_kernel_big<5, 256, false, 1> }, { 6, 256, hmcg::gibbs_sweeps_kernel_big<6, 256, false, 1> },
-    { 7, 256, hmcg::gibbs_sweeps_kernel_big<7, 256, false, 1> }, { 8, 256, hmcg::gibbs_sweeps_kernel_big<8, 256, false, 1> },
-};
-const int g_n_big_rows_variants = (int)(sizeof(g_big_rows_variants) / sizeof(g_big_rows_variants[0]));
 // ... with the backward pass every kept sweep (smoothed / filtered probability means streamed through HBM)
 const BigVariant g_big_smooth_variants[] = {
     { 2, 256, hmcg::gibbs_sweeps_kernel_big<2, 256, true> }, { 3, 256, hmcg::gibbs_sweeps_kernel_big<3, 256, true> },

@@ -272,6 +272,14 @@ def test_status_flags(hmclib, oracle):
     assert g["status"][1] == _lib.ST_NONFINITE
     assert g["status"][2] == _lib.ST_BAD_T
     assert np.isnan(g["mu"][1:]).all() and np.isnan(g["summary"][1:]).all()    # skipped windows read NaN, not a plausible zero
+    # the C ABI itself hands back zeros for a skipped window (include/hmcg.h), whatever an earlier call left in the library's
+    # recycled chunk buffers; the NaN is the Python layer's
+    Yok, Tok, _ = synth.generate_panel(3, 300, 3)
+    _lib.estimate_batch_host(Yok, Tok, 3, 0, 40, (12,), None)                                # leaves its draws in the chunk buffers
+    raw = _lib.estimate_batch_host(Y, Tw, 3, 0, 40, (12,), None, nan_fill=False, want_corr=True)
+    for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "corr"):
+        assert not raw[k][1:].any(), k
+    assert np.isfinite(raw["mu"][0]).all() and raw["mu"][0].any()
     Tbad = Tw.copy(); Tbad[0] = 301                       # longer than the panel row (ldY = 300)
     assert _lib.estimate_batch_host(Y, Tbad, 3, 2, 5, (12,), None)["status"][0] == _lib.ST_BAD_T
     xbad = np.full((3, 300), 7, dtype=np.int32)            # out-of-range initial states are clamped, not trusted

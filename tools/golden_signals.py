@@ -47,7 +47,11 @@ def load_summary_stats(noise):
     return {r["date"]: {k: float(v) for k, v in r.items() if k != "date"} for r in csv.DictReader(open(path))}
 
 
-def signal_run(noise, ns=100, burnin=1000, nrun=2000):
+def signal_run(noise, ns=100, burnin=1000, nrun=2000, sigma="fixture", base_burnin=100000, base_nrun=250000, sigma_factor=1.0):
+    """sigma = "base": sigma_signal = mean(sigma draws of the base run) * noise, the base run being estimatemodel on the window
+    with its signal set (src/Hmc.jl:868-872: HyperParams(Y,D), i.e. kappa = 1, alpha = nu = 1), at upstream's own 100k + 250k
+    sweeps -- what upstream did.  sigma = "fixture": the mean of the committed across-sample stds of the two saved signals
+    (an estimate of the same number from 2 x 100 noisy values: +-5 % per date, which the variance columns feel)."""
     y, dates = load_inflation()
     fx = load_dispersion(noise)
     use = [d for d in fx if len(fx[d]) == 1 and fx[d][0]["signalid_mean"] == 50.5]       # plain 100-sample rows
@@ -61,6 +65,16 @@ def signal_run(noise, ns=100, burnin=1000, nrun=2000):
         yreal[i, 0] = y[e + 11]
         ssig[i] = 0.5 * (fx[d][0]["signal_1_std"] + fx[d][0]["signal_2_std"])
         sig[i] = (0, e); save[i] = (e - 2, e)
+    ssig_fixture = ssig.copy()
+    ssig = ssig * sigma_factor
+    base_s = 0.0
+    if sigma == "base":
+        tb = time.perf_counter()
+        b = _lib.estimate_batch_host(Y, Tw, K, base_burnin, base_nrun, (12,), yreal, want_draws=False, sig_range=sig, kappa=1.0,
+                                     alpha=1.0, nu=1.0, window_ids=np.arange(W) + (1 << 20))
+        assert (b["status"] == 0).all()
+        ssig = b["summary"][:, K:2 * K].mean(axis=1) * float(noise)      # mean(samples.sigma) * opt.noise (:870)
+        base_s = time.perf_counter() - tb
     t0 = time.perf_counter()
     r = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), yreal, want_draws=False, sig_range=sig, save_range=save,
                                  sigma_signal=ssig, kappa=float(noise), n_samples=ns, alpha=2.0, nu=2.0, want_sample_summary=True)
@@ -71,12 +85,20 @@ def signal_run(noise, ns=100, burnin=1000, nrun=2000):
     sv = r["sigvals"]                                                    # (W, ns, 2)
     return dict(dates=use, f_mean=f.mean(axis=1), f_std=f.std(axis=1, ddof=1), e_mean=e_.mean(axis=1), sv_mean=sv.mean(axis=1),
                 sv_std=sv.std(axis=1, ddof=1), ssig=ssig, status=r["status"], wall=wall, kernel_ms=r["kernel_ms"], fx=fx, ns=ns,
-                skipped=[d for d in fx if d not in use], ss=ss, sv=sv, noise=noise, K=K)
+                skipped=[d for d in fx if d not in use], ss=ss, sv=sv, noise=noise, K=K, ssig_fixture=ssig_fixture, base_s=base_s)
 
 
-def compare_filtered(run):
+SIGMA_REL_SE = 1.0 / np.sqrt(2.0 * 99.0) / np.sqrt(2.0)      # sd of (s1 + s2) / 2 for two sample stds of 100 draws each: 5.0 %
+
+
+def compare_filtered(run, run_hi=None, hi_factor=1.05):
     """For each of the four filtered_* dispersion files: standardised difference of the across-sample mean of every column
-    (z, under "both are means of ns independent per-sample rows") and the ratio of the across-sample standard deviations."""
+    (z, under "both are means of ns independent per-sample rows") and the ratio of the across-sample standard deviations.
+    run_hi: the same run with sigma_signal scaled by hi_factor.  sigma_signal is not a committed number: upstream computed it
+    from a base run whose value does not reproduce between independent chains (tools/golden_signals_diag.py: +-12 % median,
+    a factor 2 at the 95th percentile), so it is estimated from the fixture's saved noisy signals, +-5 % per date -- and the
+    variance columns move by 2-5 standard errors for 5 %.  With run_hi the z-scores carry that input uncertainty:
+    se^2 = se_mc^2 + (d mean / d log sigma * 5 %)^2, the derivative taken from the two runs."""
     K, ns, ss = run["K"], run["ns"], run["ss"]
     cols = {"filtered_means": (slice(0, K), ["state_%d" % (i + 1) for i in range(K)]),
             "filtered_variances": (slice(K, 2 * K), ["state_%d" % (i + 1) for i in range(K)]),
@@ -91,7 +113,13 @@ def compare_filtered(run):
         ours = ss[:, :, sl]
         m, sd = ours.mean(axis=1), ours.std(axis=1, ddof=1)
         se = np.sqrt(sd ** 2 + ref_s ** 2) / np.sqrt(ns)
-        out[var] = dict(z=(m - ref_m) / np.maximum(se, 1e-300), diff=m - ref_m, ratio=sd / np.maximum(ref_s, 1e-300), ref_m=ref_m, ref_s=ref_s, m=m, sd=sd)
+        se_in = 0.0
+        if run_hi is not None:
+            sens = (run_hi["ss"][:, :, sl].mean(axis=1) - m) / np.log(hi_factor)
+            se_in = np.abs(sens) * SIGMA_REL_SE
+        se_t = np.sqrt(se ** 2 + se_in ** 2)
+        out[var] = dict(z=(m - ref_m) / np.maximum(se_t, 1e-300), z_mc=(m - ref_m) / np.maximum(se, 1e-300), diff=m - ref_m,
+                        ratio=sd / np.maximum(ref_s, 1e-300), ref_m=ref_m, ref_s=ref_s, m=m, sd=sd, se_in=se_in, se_mc=se)
     return out
 
 
@@ -131,7 +159,9 @@ def compare(run):
 
 if __name__ == "__main__":
     # usage: golden_signals.py [noise ...] [burnin=N] [nrun=N]
-    kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+    kw = {a.split("=")[0]: (a.split("=")[1] if a.startswith("sigma=") else int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a}
+    if "nrun" not in kw:
+        kw["nrun"] = 2000
     for noise in ([a for a in sys.argv[1:] if "=" not in a] or ["0.1", "0.3", "0.6"]):
         run = signal_run(noise, **kw)
         c = compare(run)
@@ -142,10 +172,15 @@ if __name__ == "__main__":
               " mean z %.3f  rms z %.3f" % (c["z_mean"].mean(), np.sqrt((c["z_mean"] ** 2).mean())))
         print("   max |diff| %.4f; std ratio quantiles" % np.abs(c["diff"]).max(), q(c["ratio"]), "geo-mean %.3f" % np.exp(np.log(c["ratio"]).mean()))
         print("   z(signal means) rms %.3f %.3f" % (np.sqrt((c["zs1"] ** 2).mean()), np.sqrt((c["zs2"] ** 2).mean())))
-        for var, r in compare_filtered(run).items():
-            az = np.abs(r["z"])
-            print("   %-22s |z| median %.2f  q99 %.2f  max %.2f | mean z per column %s | std ratio median per column %s" % (
-                var, np.median(az), np.quantile(az, 0.99), az.max(), np.round(r["z"].mean(axis=0), 2), np.round(np.median(r["ratio"], axis=0), 2)))
+        rr = run["ssig_fixture"] / run["ssig"]
+        print("   sigma_signal: fixture's across-sample std of the saved signals / ours: median %.4f, quantiles 5%%/95%% %.3f %.3f (base run %.1f s)" % (
+            np.median(rr), np.quantile(rr, 0.05), np.quantile(rr, 0.95), run["base_s"]))
+        run_hi = signal_run(noise, **dict(kw, sigma_factor=1.05)) if kw.get("sigma", "fixture") == "fixture" else None
+        for var, r in compare_filtered(run, run_hi).items():
+            az, am = np.abs(r["z"]), np.abs(r["z_mc"])
+            print("   %-22s |z| median %.2f q99 %.2f max %.2f (Monte-Carlo error alone: median %.2f q99 %.2f) | mean z per column %s | std ratio median per column %s" % (
+                var, np.median(az), np.quantile(az, 0.99), az.max(), np.median(am), np.quantile(am, 0.99), np.round(r["z"].mean(axis=0), 2),
+                np.round(np.median(r["ratio"], axis=0), 2)))
         try:
             cs = compare_summary_rows(run)
             print("   forecasts_summary rows: quartile z rms", {p: round(float(np.sqrt((z ** 2).mean())), 3) for p, z in cs["zq"].items()},
