@@ -21,7 +21,7 @@ FLAG_RESUME = 1
 ST_BAD_INVGAMMA, ST_EMIS_UNDERFLOW, ST_NONFINITE, ST_GAMMA_CAP, ST_BAD_T, ST_BAD_RANGE = 1, 2, 4, 8, 16, 32
 ST_SKIPPED = ST_NONFINITE | ST_BAD_T | ST_BAD_RANGE      # the window was not computed at all
 
-HMCG_MAXTAIL = 32
+HMCG_MAXTAIL = 256
 EXPORTS = ("hmcg_version", "hmcg_device_count", "hmcg_last_error", "hmcg_shutdown",
            "hmcg_estimate_batch", "hmcg_estimate_batch_device", "hmcg_estimate_batch_multi",
            "hmcg_save_results_csv", "hmcg_write_table_csv", "hmcg_format_float")

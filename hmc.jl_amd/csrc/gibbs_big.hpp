@@ -115,7 +115,16 @@ __device__ __forceinline__ void count_le_sorted_batch(const double (&c)[K][K], c
     for (int s = 0; s < K; ++s) idx[s] = (b1[s] ? 4 : 0) + (b2[s] ? 2 : 0) + ((m3[s] <= thr[s]) ? 1 : 0);
 }
 
-template <int K, int NT, bool SM = false>
+// Where the per-step arrays (observations, uniforms, state maps, states) live: LDS, or -- STREAM -- the window's slab of an
+// HBM scratch (global address space, so that the accesses are global_*, never flat_*): the same code either way.
+template <bool GLOBAL, class T> struct StepPtr { using type = T*; };
+template <class T> struct StepPtr<true, T> { using type = __attribute__((address_space(1))) T*; };
+
+// STREAM: the window is longer than the CU's LDS holds (T beyond ~6 500 at K = 8, ~7 500 at K = 3): Y, the sweep's uniforms,
+// the state maps and the states stream through HBM / L2 (each lane walks its own L consecutive steps, so a cache line
+// serves eight of them); slower per step than the LDS-resident form, but no longer refused (the reference's loops are
+// unbounded in N, src/Hmc.jl:406).
+template <int K, int NT, bool SM = false, bool STREAM = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
     static_assert(K >= 2 && K <= 8, "4-bit map entries: K <= 8 (K <= 4 normally runs on the register-resident kernel; this one\n"
@@ -128,10 +137,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     __shared__ Sh sh;
     extern __shared__ double dyn_lds[];
     const int cap = NT * L;
-    double* const ylds = dyn_lds;                                   // [cap] observations
-    double* const uxs = dyn_lds + cap;                              // [cap] uniforms of the running sweep
-    uint32_t* const maps = reinterpret_cast<uint32_t*>(dyn_lds + 2 * (size_t)cap);   // [cap] state maps g_t
-    uint8_t* const xs = reinterpret_cast<uint8_t*>(maps + cap);     // [cap + 8] states
+    using DPtr = typename StepPtr<STREAM, double>::type;
+    using UPtr = typename StepPtr<STREAM, uint32_t>::type;
+    using BPtr = typename StepPtr<STREAM, uint8_t>::type;
+    DPtr ylds;                                                      // [cap] observations
+    if constexpr (STREAM) ylds = (DPtr)(p.sscr + (size_t)blockIdx.x * (size_t)p.stream_stride);
+    else ylds = (DPtr)dyn_lds;
+    const DPtr uxs = ylds + cap;                                    // [cap] uniforms of the running sweep
+    const UPtr maps = (UPtr)(ylds + 2 * (size_t)cap);               // [cap] state maps g_t
+    const BPtr xs = (BPtr)(maps + cap);                             // [cap + 8] states
     // HBM scratch of this thread's per-step pdfs, [L][K] with the thread index fastest (p.fscr is [W][L][K][NT])
     double* const fscr = p.fscr + (size_t)blockIdx.x * L * K * NT + threadIdx.x;
 

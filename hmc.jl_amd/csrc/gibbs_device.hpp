@@ -88,7 +88,14 @@ struct KernelParams {
     // LDS-resident kernel (gibbs_big.hpp) only: scratch that hands each step's K pdfs from the product phase to the replay,
     // [W][L][K][NT] (thread index fastest: coalesced); library-owned
     double* fscr;
+    // ... and its HBM-streaming variant (windows whose per-step state does not fit the CU's LDS): per window the observations,
+    // the sweep's uniforms, the state maps and the states, [W][stream_stride] bytes; library-owned
+    uint8_t* sscr;
+    int64_t stream_stride;
 };
+
+// bytes of one window's slab of KernelParams::sscr for `cap` = NT * L steps (observations | uniforms | maps | states + 8)
+__host__ __device__ inline size_t stream_slab_bytes(size_t cap) { return (cap * (8 + 8 + 4) + cap + 8 + 255) & ~(size_t)255; }
 
 // index of the kept draw produced by global sweep g, or -1 during burn-in
 __device__ __forceinline__ int kept_index(const KernelParams& p, int g)

@@ -237,6 +237,7 @@ struct Plan {
     const Variant* v = nullptr;
     const BigVariant* bv = nullptr;
     int bigL = 0;
+    bool stream = false;           // the LDS-resident kernel's HBM-streaming form (window too long for the CU's LDS)
     size_t dyn = 0;
     bool use_sig = false, use_smooth = false;
     bool needs_pif() const { return bv != nullptr && use_smooth; }   // the LDS-resident smoothing kernel streams pif through pif_final
@@ -245,6 +246,9 @@ struct Plan {
     int NH() const { return v ? v->NH : 0; }
     // LDS-resident kernel: per-step pdfs handed from the product phase to the replay, [W][L][K][NT] doubles
     size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)K * (size_t)bv->NT : 0; }
+    // streaming form: per window the observations, uniforms, state maps and states of its NT * L steps
+    size_t slab_bytes() const { return stream ? hmcg::stream_slab_bytes((size_t)bv->NT * (size_t)bigL) : 0; }
+    size_t stream_bytes(int W) const { return slab_bytes() * (size_t)W; }
     const void* fptr() const { return v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn); }
 };
 
@@ -301,7 +305,15 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
             // dynamic + static LDS of the instantiation must fit the CU's 160 KiB
             hipFuncAttributes fa{};
             const size_t stat = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pl.bv->fn)) == hipSuccess ? fa.sharedSizeBytes : 48 * 1024;
-            if (pl.dyn + stat > 160 * 1024 || (cfg->threads_per_window != 0 && cfg->threads_per_window != pl.bv->NT)) pl.bv = nullptr;
+            if (cfg->threads_per_window != 0 && cfg->threads_per_window != pl.bv->NT) pl.bv = nullptr;
+            else if (pl.dyn + stat > 160 * 1024 || getenv("HMCG_FORCE_STREAM")) {
+                // too long for the LDS: the same kernel with its per-step arrays in an HBM scratch (HMCG_FORCE_STREAM: tests)
+                pl.bv = nullptr;
+                if (!use_smooth)
+                    for (int i = 0; i < g_n_big_stream_variants; ++i) if (g_big_stream_variants[i].K == cfg->K) pl.bv = &g_big_stream_variants[i];
+                pl.stream = pl.bv != nullptr;
+                pl.dyn = 16;
+            }
         }
     }
     if (!pl.v && !pl.bv) {
@@ -453,10 +465,12 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
     if (uses_scratch) HIP_TRY(hipStreamWaitEvent(stream, c.ev_scr, 0));
     if (pl.bv) {
         HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
-        const size_t sbytes = pl.scratch_bytes(cfg->W, cfg->K);
+        const size_t fbytes = (pl.scratch_bytes(cfg->W, cfg->K) + 255) & ~(size_t)255;
+        const size_t sbytes = fbytes + pl.stream_bytes(cfg->W);
         if (c.scr.cap < sbytes) HIP_TRY(hipStreamSynchronize(stream));        // growing the scratch frees the old one
         if (c.scr.ensure(sbytes)) { set_err("workspace allocation failed (%zu B device)", sbytes); return HMCG_E_NOMEM; }
         p.fscr = reinterpret_cast<double*>(c.scr.base);
+        if (pl.stream) { p.sscr = reinterpret_cast<uint8_t*>(c.scr.base + fbytes); p.stream_stride = (int64_t)pl.slab_bytes(); }
     }
     if (timing) HIP_TRY(hipEventRecord(c.ev0, stream));
 #ifdef HMCG_STAMPS
@@ -604,6 +618,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     for (int r = 0; r < nring; ++r) o_dchunk[r] = LD.add(chunk_bytes);
     const size_t o_dmom = want_corr ? LD.add(8 * N * mom_stride) : 0, o_dcorr = want_corr ? LD.add(8 * N * NCC * NCC) : 0;
     const size_t o_dfs = pl.bv ? LD.add(pl.scratch_bytes(n, cfg->K)) : 0;
+    const size_t o_dstr = pl.stream ? LD.add(pl.stream_bytes(n)) : 0;
     // pinned staging beyond the input block: small outputs (status | summary adjacent, as on the device), chunk ring, extras
     const size_t o_pst = LP.add(4 * N);
     const size_t o_psum = h.summary ? LP.add(8 * N * NS) : 0;
@@ -688,6 +703,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
                                           DP(int32_t, o_dst), &dex, pl.use_sig);
     base.summary = h.summary ? DP(double, o_dsum) : nullptr;
     if (pl.bv) base.fscr = DP(double, o_dfs);
+    if (pl.stream) { base.sscr = DP(uint8_t, o_dstr); base.stream_stride = (int64_t)pl.slab_bytes(); }
     if (pl.bv) HIP_TRY(hipFuncSetAttribute(pl.fptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn));
 
     // ---- the chunk pipeline ----

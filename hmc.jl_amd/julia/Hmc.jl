@@ -76,7 +76,7 @@ struct hmcg_extras
     pi_filter_mean::Ptr{Float64}
     corr::Ptr{Float64}
 end
-const HMCG_MAXTAIL = 32
+const HMCG_MAXTAIL = 256
 const HMCG_MAXDEV = 16
 
 struct hmcg_timing                    # include/hmcg.h (ABI 104)

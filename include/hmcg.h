@@ -55,7 +55,7 @@ extern "C" {
 
 #define HMCG_VERSION 105
 #define HMCG_MAXH 8
-#define HMCG_MAXTAIL 32         /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
+#define HMCG_MAXTAIL 256        /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
 #define HMCG_MAXDEV 16           /* devices one process may drive */
 

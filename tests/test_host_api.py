@@ -60,7 +60,9 @@ def test_estopt_defaults_and_accessors():
     assert hmc.yobs(o, 133) == 133.0 and hmc.yend(o, 2) == 123.0
     o2 = hmc.estopt(raw, dates, sampleRange=range(1, 51), signalRange=range(49, 51), endIndex=48)
     assert o2.obsRange == list(range(1, 49))
-    o3 = hmc.estopt(raw, dates, sampleRange=range(1, 101), signalRange=range(60, 101), endIndex=60)   # sigLen = 40 > HMCG_MAXTAIL
+    raw3 = np.arange(1.0, 401.0)
+    dates3 = [hmc.makedate(120 + i) for i in range(400)]
+    o3 = hmc.estopt(raw3, dates3, sampleRange=range(1, 361), signalRange=range(61, 361), endIndex=60)   # sigLen = 300 > HMCG_MAXTAIL
     with pytest.raises(NotImplementedError):
         hmc.estimatemodel(o3)
     o4 = hmc.estopt(raw, dates, sampleRange=range(1, 51), signalRange=range(40, 45), endIndex=50)     # not a tail of the window
