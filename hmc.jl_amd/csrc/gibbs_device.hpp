@@ -139,9 +139,12 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 
 // exp(x), x <= 0, with a table of 2^(j/N) held in LDS: x = (N e + j) ln2/N + r, |r| <= ln2/(2N), exp(r) by a
 // Taylor polynomial, result 2^e * tab[j] * poly: ~1 ulp.  N = 64 with degree 5 (truncation 3.5e-17) or N = 256 with
-// degree 4 (3.8e-17).
+// degree 4 (3.8e-17).  256 entries are the default (one FMA less per exponential: +1.5 % on the headline kernel, +0.9 % at
+// K = 8; tools/ab.sh, tools/ab_shapes.sh); a translation unit may define HMCG_EXPTAB_N 64 ahead of this header -- the one that
+// holds the K = 3, 16-steps-per-thread variants does, because with 256 entries the backend's register-allocation fault
+//  strikes its capped flavour (16 spill stores ahead of an exec restore; isa_lint refuses the build).
 #ifndef HMCG_EXPTAB_N
-#define HMCG_EXPTAB_N 64
+#define HMCG_EXPTAB_N 256
 #endif
 constexpr int EXPTAB_N = HMCG_EXPTAB_N;
 static_assert(EXPTAB_N == 64 || EXPTAB_N == 256, "exp table: 64 or 256 entries");

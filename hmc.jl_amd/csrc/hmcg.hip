@@ -188,7 +188,7 @@ void destroy_context(DeviceCtx& c)
 using namespace hmcg_host;
 using namespace hmcg_hostutil;
 int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
-const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
+const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k3_l16, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
 
 
 // The variant for (K, longest window, threads per window, path): the fewest steps per thread that cover the

@@ -4,7 +4,7 @@
 namespace hmcg_host {
 static const Variant k3[] = {
     HMCG_V3(3, 1, false, false, H, P2), HMCG_V3(3, 2, false, false, H, P1), HMCG_V3(3, 4, false, false, H, P2),
-    HMCG_V3(3, 8, false, false, H, P2),                 // (16 steps per thread: variants_k3_l16.hip, with the 64-entry exp table)
+    HMCG_V3(3, 8, false, false, H, P2), HMCG_V3(3, 16, false, false, P1, P2),
     HMCG_V(3, 2, 512, false, false, 0, 1, P1, P1), HMCG_V(3, 8, 128, false, false, 0, 2, P2, P2),
 };
 HMCG_GROUP(g_group_k3, k3);

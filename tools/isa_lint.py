@@ -16,6 +16,15 @@ register allocation, i.e. on unrelated source changes, so every build is checked
           call (an un-inlined lambda captures by reference: flat accesses, a stack, s_swappc).
 Kernels that spill to scratch are listed as warnings (a performance matter, not a correctness one).
 
+Every rule-1 hit is classified by a walk over the divergent region it closes: the exec restore names the SGPR pair that
+holds the saved mask; the walk goes back to the instruction that saved it (s_and_saveexec_b64 / s_mov_b64 sN, exec / s_xor
+...) and asks whether the copied VALUE (the copy's source registers) was written inside that region.  If it was, the copy is
+"phi-like": the value exists only in the lanes that are active there, and copying it under their mask is what a PHI needs.
+If it was not -- the value is live-in from before the branch, every lane holds one -- the copy (or spill) under the narrow
+mask loses the other lanes' values: "live-in", the round-1 fault.  When the saving instruction cannot be found (the mask came
+back from an SGPR spill lane) the hit counts as live-in.  Both classes fail the build; --allow-phi lets phi-like ones pass
+(diagnostics: to see whether a refused build is refused on the real pattern).
+
 Exit status 1 when a rule fails.  Also prints, per kernel, VGPR/AGPR/spill/scratch/LDS figures (--table).
 """
 import glob
@@ -43,7 +52,62 @@ BLOCK_START = re.compile(r"^(\.LBB\d+_\d+:|; %bb\.\d+:|[_A-Za-z][\w$.]*:)")
 KERNEL_START = re.compile(r"^(_Z\w+):\s")
 
 
-def lint_file(path):
+def _regs(tok):
+    """register numbers named by one operand token: v12 -> {12}, v[4:7] -> {4..7}, a3 -> {} (only VGPRs matter here)"""
+    m = re.match(r"^-?\|?v(\d+)\|?$", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.match(r"^-?\|?v\[(\d+):(\d+)\]\|?$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def _operands(s):
+    body = s.split(None, 1)
+    return [t.strip() for t in body[1].split(",")] if len(body) > 1 else []
+
+
+def _copy_sources(s):
+    """VGPRs whose VALUE a register-allocator copy / spill moves"""
+    ops = _operands(s)
+    if s.startswith(("scratch_store", "buffer_store")):
+        return set().union(*[_regs(t) for t in ops[:2]]) if ops else set()
+    if s.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_write")):
+        return _regs(ops[1]) if len(ops) > 1 else set()
+    return set()          # reloads (scratch_load, v_accvgpr_read): the value comes from memory / an AGPR -- treated as live-in
+
+
+def classify(lines, copy_idx, widen_idx):
+    """'phi-like' if every source register of the copy at lines[copy_idx] is written inside the divergent region that the
+    exec restore at lines[widen_idx] closes, else 'live-in'."""
+    m = re.search(r"exec,\s*exec,\s*(s\[\d+:\d+\])", lines[widen_idx]) or re.search(r"s_or_saveexec_b64\s+\S+,\s*(s\[\d+:\d+\])", lines[widen_idx])
+    if not m:
+        return "live-in"
+    mask = re.escape(m.group(1))
+    src = _copy_sources(lines[copy_idx].split(";")[0].strip())
+    if not src:
+        return "live-in"
+    written = set()
+    for k in range(copy_idx - 1, max(copy_idx - 20000, -1), -1):
+        t = lines[k].split(";")[0].strip()
+        if not t or t.startswith("."):
+            if KERNEL_START.match(lines[k]):
+                break
+            continue
+        if re.match(r"^(s_and_saveexec_b64|s_or_saveexec_b64|s_xor_saveexec_b64)\s+" + mask, t) or re.match(r"^s_mov_b64\s+" + mask + r",\s*exec", t) \
+                or re.match(r"^s_(and|xor|andn2)_b64\s+" + mask + r",\s*exec", t):
+            return "phi-like" if src <= written else "live-in"
+        if re.match(r"^(v_readlane_b32|s_load|s_mov_b64|s_mov_b32)\s+s", t) and re.search(mask.replace("\\[", "").split(":")[0] + r"\b", t.split(",")[0]):
+            return "live-in"          # the mask came back from somewhere else: region start unknown
+        if t.startswith(("v_", "ds_read", "ds_bpermute", "ds_swizzle", "global_load", "scratch_load", "buffer_load")) and not t.startswith(("v_cmp", "v_writelane")):
+            ops = _operands(t)
+            if ops:
+                written |= _regs(ops[0])
+    return "live-in"
+
+
+def lint_file(path, allow_phi=False):
     problems, table = [], []
     kernel = None
     in_prologue = False
@@ -75,7 +139,10 @@ def lint_file(path):
             if EXEC_WIDEN.match(line):
                 if pending:
                     for pn, ps in pending:
-                        problems.append((path, pn, kernel, "vector spill/copy ahead of the exec restore at line %d" % n, ps))
+                        kind = classify(lines, pn - 1, n - 1)
+                        if kind == "phi-like" and allow_phi:
+                            continue
+                        problems.append((path, pn, kernel, "vector spill/copy ahead of the exec restore at line %d [%s]" % (n, kind), ps))
                 in_prologue = False      # one exec restore per prologue is what the backend emits; stop here
             elif EXEC_OTHER.match(line):
                 in_prologue = False      # exec narrowed / rewritten: not the join pattern
@@ -118,7 +185,7 @@ def main():
         return 2
     bad = 0
     for p in paths:
-        problems, table = lint_file(p)
+        problems, table = lint_file(p, allow_phi="--allow-phi" in sys.argv)
         if "--table" in sys.argv:
             for k in table:
                 print("%-34s vgpr %3d agpr %3d vspill %3d sspill %3d scratch %4d lds %6d" % (
