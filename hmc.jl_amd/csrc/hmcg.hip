@@ -778,11 +778,17 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         launch_kernel(pl, p, s);
         HIP_TRY(hipGetLastError());
         if (stream_draws) {
-            HIP_TRY(hipEventRecord(c.evk[slot], s));
-            HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
+            // the last chunk's copy-out hides behind nothing: it goes on the compute stream itself, right behind its kernel,
+            // instead of paying a cross-stream event hand-off at the tail of the call
+            const bool tail_copy = cidx == nch - 1 && !want_corr && getenv("HMCG_NO_TAIL_COPY") == nullptr;
+            hipStream_t cs = tail_copy ? s : c.copy;
+            if (!tail_copy) {
+                HIP_TRY(hipEventRecord(c.evk[slot], s));
+                HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
+            }
             if (ndc > 0 && copy_out)
-                HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, c.copy));
-            HIP_TRY(hipEventRecord(c.evc[slot], c.copy));
+                HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, cs));
+            HIP_TRY(hipEventRecord(c.evc[slot], cs));
             if (want_corr && ndc > 0) {
                 // second moments of the chunk's rounded draws, in HBM, beside the chunk's copy-out (calccorr)
                 hmcg_host::MomentsArgs ma{p.mu, p.sig2, p.pi_end, p.A, p.fcast, DP(double, o_dmom), (long long)ndc, (long long)ndc,

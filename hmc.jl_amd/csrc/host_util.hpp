@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -107,11 +108,17 @@ inline std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int n
     long long fdiv = 32;       // (measured at the headline shape: 1/8 5.34 ms, 1/16 5.30, 1/32 5.23 per call)
     if (const char* e = getenv("HMCG_CHUNK_FLOOR_DIV")) { const long long v = atoll(e); if (v >= 2 && v <= 1024) fdiv = v; }
     const long long floor_sz = std::max(16LL, nd / fdiv);
+    // share of the remaining draws a chunk takes (HMCG_CHUNK_KEEP=num/den, diagnostics; default 1/2)
+    long long keep_num = 1, keep_den = 2;
+    if (const char* e = getenv("HMCG_CHUNK_KEEP")) {
+        long long a = 0, b = 0;
+        if (sscanf(e, "%lld/%lld", &a, &b) == 2 && a >= 1 && b > a && b <= 64) { keep_num = a; keep_den = b; }
+    }
     long long d = dB;
     int s = sb;
     while (d < dE) {
         const long long rem = dE - d;
-        long long take = std::min(cap, std::max((rem + 1) / 2, floor_sz));
+        long long take = std::min(cap, std::max((rem * keep_num + keep_den - 1) / keep_den, floor_sz));
         if (rem - take < floor_sz / 2) take = std::min(cap, rem);       // no crumbs
         take = std::min(take, rem);
         const long long d1 = d + take;

@@ -15,7 +15,7 @@ with tempfile.TemporaryDirectory() as tmp:
         f.write(struct.pack("<20i", *hd)); f.write(struct.pack("<3d", 0.0, 0.0, 0.0))
         f.write(np.ascontiguousarray(Y, dtype="<f8").tobytes()); f.write(np.ascontiguousarray(Tw, dtype="<i4").tobytes())
         f.write(np.ascontiguousarray(yreal, dtype="<f8").tobytes())
-    env = dict(os.environ, HMCG_TRACE="1"); env.pop("LD_PRELOAD", None)
+    env = dict(os.environ); env.setdefault("HMCG_TRACE", "1"); env.pop("LD_PRELOAD", None)      # HMCG_TRACE= (empty) still traces; unset it in the library by not exporting
     r = subprocess.run([os.path.join(ROOT, "tests", "cdriver", "hmcg_cdriver"), req, os.path.join(tmp, "resp.bin")], capture_output=True, text=True, env=env)
 print(r.stdout)
 print("\n".join(r.stderr.splitlines()[-5:]))
