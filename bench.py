@@ -87,11 +87,12 @@ def cpu_baseline(Y, Tw, yreal):
 
 
 def kernel_name(K_, tm, sig=False, smooth=False):
-    if K_ >= 5 or tm.steps_per_thread > 16:
-        return "hmcg::gibbs_sweeps_kernel_big<%d,%d>" % (K_, tm.threads_per_window)
+    """The instantiation that ran, as rocprofv3 names it (template arguments from the call's own timing record)."""
+    if tm.occupancy == 0:          # the LDS-resident kernel: <K, NT, SM, STREAM, SIG>
+        return "hmcg::gibbs_sweeps_kernel_big<%d,%d,%s,%s,%s>" % (K_, tm.threads_per_window, str(smooth).lower(),
+                                                                  str(tm.lds_bytes < 21 * tm.threads_per_window * tm.steps_per_thread).lower(), str(sig).lower())
     return "hmcg::gibbs_sweeps_kernel<%d,%d,%d,%s,%s,%d,%d>" % (
-        K_, tm.steps_per_thread, tm.threads_per_window, str(sig).lower(), str(smooth).lower(), tm.helper_waves,
-        2 if tm.helper_waves else 0)
+        K_, tm.steps_per_thread, tm.threads_per_window, str(sig).lower(), str(smooth).lower(), tm.helper_waves, tm.occupancy)
 
 
 def shape_record(name, K_, lens, draws, reps=3, device=0):

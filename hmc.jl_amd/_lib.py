@@ -53,7 +53,7 @@ class Extras(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int32), ("threads_per_window", C.c_int32),
                 ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32), ("helper_waves", C.c_int32),
-                ("device", C.c_int32), ("call_ms", C.c_double), ("windows", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("call_ms", C.c_double), ("windows", C.c_int32), ("occupancy", C.c_int32)]
 
 
 _LIB = None

@@ -373,7 +373,7 @@ void fill_timing(hmcg_timing* t, const Plan& pl, const DeviceCtx& c, double kern
     t->device = c.device;
     t->call_ms = call_ms;
     t->windows = windows;
-    t->reserved = 0;
+    t->occupancy = pl.v ? pl.v->occ : 0;
     t->lds_bytes = 0;
     hipFuncAttributes fa{};
     if (hipFuncGetAttributes(&fa, pl.fptr()) == hipSuccess) t->lds_bytes = (int32_t)(fa.sharedSizeBytes + pl.dyn);

@@ -90,7 +90,7 @@ struct hmcg_timing                    # include/hmcg.h (ABI 105)
     device::Int32
     call_ms::Float64
     windows::Int32
-    reserved::Int32
+    occupancy::Int32
 end
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))

@@ -177,7 +177,8 @@ typedef struct hmcg_timing {
     double call_ms;          /* host entries: wall time of the whole call on this device -- staging, H2D, kernels, D2H and the
                                 scatter into the caller's arrays (0 for the device entry) */
     int32_t windows;         /* windows this device ran */
-    int32_t reserved;
+    int32_t occupancy;       /* register-resident kernels: 1 = the whole register file per window, 2 = capped so that two windows
+                                share a CU (the OCC template argument of the kernel that ran); 0 for the LDS-resident kernel */
 } hmcg_timing;
 
 int hmcg_version(void);
