@@ -261,12 +261,16 @@ def estimatesignals(opt, device=0):
     return s
 
 
-def estimatesignalswindows(opts, device=0, window_ids=None):
+def estimatesignalswindows(opts, device=0, window_ids=None, keep_draws=True, summaries=False):
     """estimatesignals! for many windows in one GPU call (what the reference fans out as one SLURM task per end date,
     slurmscripts/base_estimation.sh:5): opts is a list of estopt with signal ranges that share D, horizons, the sweep
     counts, noiseSamples, noise, seed and sigLen.  Windows whose opt.σsignal is 0 get it from a batched base run first
     (:869-872).  Returns the list of Samples in the order of opts.  RNG stream ids default to the position in `opts`
-    (pass window_ids = zeros to reproduce single-window estimatesignals calls draw for draw)."""
+    (pass window_ids = zeros to reproduce single-window estimatesignals calls draw for draw).
+    summaries=True additionally returns, as a second value, a dict with `sample_summary` (W, noiseSamples, 3K+K^2+2H) -- per
+    noise sample the mean of its signalNrun rounded draws, taken on the device: the rows runaggregate(datadir, var) makes per
+    (date, signalid) (src/Hmc.jl:1053-1075); write_signal_summaries writes them as upstream's files -- and `signalvals`
+    (W, noiseSamples, len(signalSave)).  With keep_draws=False no draw leaves the GPU and the first value is None."""
     o0 = opts[0]
     W = len(opts)
     for o in opts:
@@ -303,19 +307,30 @@ def estimatesignalswindows(opts, device=0, window_ids=None):
     kw = dict(end_pos=[o.endIndex - 1 for o in opts], blend_mask=blend) if sigLen > 0 else {}
     res = _lib.estimate_batch_host(Y, Tw, o0.D, o0.signalburnin, n, tuple(dev_h), yreal, seed=o0.seed, device=device,
                                    window_ids=wid, sig_range=sig, save_range=sv, sigma_signal=[o.σsignal for o in opts],
-                                   kappa=o0.noise, n_samples=ns, alpha=2.0, nu=2.0, **kw)
+                                   kappa=o0.noise, n_samples=ns, alpha=2.0, nu=2.0, want_draws=bool(keep_draws),
+                                   want_sample_summary=bool(summaries), **kw)
     _check_status(res["status"], "estimatesignalswindows")
+    nsave = len(o0.signalSave)
+    NP = 3 * o0.D + o0.D * o0.D
+    extra = None
+    if summaries:
+        ss = res["sample_summary"].copy()
+        for k, h in enumerate(o0.horizons):
+            if h < sigLen:
+                ss[:, :, NP + 2 * k:NP + 2 * k + 2] = np.nan
+        extra = dict(sample_summary=ss, signalvals=res["sigvals"][:, :, :nsave].copy())
+    if not keep_draws:
+        return None, extra
     for k, h in enumerate(o0.horizons):
         if h < sigLen:
             res["fcast"][:, 2 * k:2 * k + 2] = np.nan
     out = []
-    nsave = len(o0.signalSave)
     for w, o in enumerate(opts):
         s = _unpack(res, w, ns * n, o.D, len(o.horizons), enddate(o))
         s.signalvals = np.repeat(res["sigvals"][w][:, :nsave], n, axis=0)
         s.signalids = np.repeat(np.arange(1, ns + 1), n)
         out.append(s)
-    return out
+    return (out, extra) if summaries else out
 
 
 class BatchResult:
@@ -486,6 +501,45 @@ def write_summaries(summary, opts, dir, legacy_trans_header=False):
             f.write(",".join(["date"] + [h + "_mean" for h in hdr]) + "\n")
             for w in order:
                 f.write(",".join([str(enddate(opts[w]))] + [_fmt(v) for v in summary[w, a:b]]) + "\n")
+        paths.append(p)
+    return paths
+
+
+def write_signal_summaries(sample_summary, signalvals, opts, dir, legacy_trans_header=False):
+    """The five `<var>_summary.csv` files runaggregate(datadir, var) (src/Hmc.jl:1053-1075) writes for a SIGNAL run -- header
+    `date,signalid,<col>_mean...,signal_1_mean...`, one row per (date, noise sample), dates in ascending order as the per-draw
+    files sort -- straight from the device's per-sample means (estimatesignalswindows(..., summaries=True)): the
+    noiseSamples x signalNrun x 5 files of per-draw text per date are not needed.  The signal columns are constant within a
+    sample; their "mean" is still taken as the file route takes it (the rounded value summed signalNrun times, divided), so
+    that both routes print the same text (upstream's own fixture shows the effect: signal_1_mean = 12.408199999956814)."""
+    os.makedirs(dir, exist_ok=True)
+    o0 = opts[0]
+    K, H = o0.D, len(o0.horizons)
+    h1, h2, h3 = _header(o0, 2 * H)
+    if legacy_trans_header:
+        h2 = ["trans_%d_%d" % (j, i) for j in range(1, K + 1) for i in range(1, K + 1)]
+    cols = [(0, K, h1), (K, 2 * K, h1), (2 * K, 3 * K, h1), (3 * K, 3 * K + K * K, h2),
+            (3 * K + K * K, 3 * K + K * K + 2 * H, h3)]
+    ns, nsave = sample_summary.shape[1], signalvals.shape[2]
+    n = o0.signalNrun
+
+    def const_mean(r):                                    # _seq_mean([r] * n) without the list
+        if n <= 4096:
+            acc = 0.0
+            for _ in range(n):
+                acc += r
+            return acc / n
+        return float(np.cumsum(np.full(n, r))[-1]) / n    # (cumsum adds in sequence)
+    order = sorted(range(len(opts)), key=lambda w: enddate(opts[w]))
+    paths = []
+    for name, (a, b, hdr) in zip(SUMMARY_FILES, cols):
+        p = os.path.join(dir, name + "_summary.csv")
+        with open(p, "w") as f:
+            f.write(",".join(["date", "signalid"] + [h + "_mean" for h in hdr] + ["signal_%d_mean" % (i + 1) for i in range(nsave)]) + "\n")
+            for w in order:
+                for smp in range(ns):
+                    f.write(",".join([str(enddate(opts[w])), str(smp + 1)] + [_fmt(v) for v in sample_summary[w, smp, a:b]] +
+                                     [_fmt(const_mean(float(np.rint(v * 1e5) / 1e5))) for v in signalvals[w, smp]]) + "\n")
         paths.append(p)
     return paths
 

@@ -173,3 +173,32 @@ def test_smoothed_state_probabilities_host_api(hmclib, oracle, inflation, tmp_pa
     hmc.savesmoothresults(s.πb_mean, dd[:e], str(tmp_path))
     lines = open(tmp_path / "smoothed_state_probs.csv").read().splitlines()
     assert lines[0] == "Date,state_1,state_2,state_3" and len(lines) == e + 1 and lines[1].startswith("1970-01-01,")
+
+
+def test_signal_summaries_from_the_device_equal_the_file_route(hmclib, tmp_path):
+    """runaggregate(datadir, var) on a signal run (src/Hmc.jl:1053-1075: group the per-draw rows by date and signalid, mean)
+    two ways: (a) as upstream -- saveresults(hassignals=true) writes the per-draw files, runaggregate reads them back;
+    (b) estimatesignalswindows(..., summaries=True) takes the per-sample means on the device (extras.sample_summary) and
+    write_signal_summaries prints them.  The five files must be identical byte for byte; (b) with keep_draws=False as well,
+    where no draw leaves the GPU."""
+    raw = np.array([5.0 + np.sin(i / 7.0) * 2 + (i % 13) * 0.3 for i in range(260)])
+    dates = [hmc.makedate(120 + i) for i in range(260)]
+    opts = [hmc.estopt(raw, dates, sampleRange=range(1, e + 1), signalRange=range(e - 20, e + 1), signalSave=range(e - 1, e + 1),
+                       endIndex=e, horizons=[12], D=3, burnin=30, Nrun=60, signalburnin=5, signalNrun=23, noiseSamples=4, noise=0.3,
+                       series="t") for e in (150, 201, 177)]
+    samples, extra = hmc.estimatesignalswindows(opts, summaries=True)
+    a, b = tmp_path / "files", tmp_path / "device"
+    for s_, o in zip(samples, opts):
+        hmc.saveresults(s_, o, str(a), hassignals=True)
+    for var in hmc.SUMMARY_FILES:
+        hmc.runaggregate(str(a), var)
+    hmc.write_signal_summaries(extra["sample_summary"], extra["signalvals"], opts, str(b))
+    for var in hmc.SUMMARY_FILES:
+        ta, tb = open(a / (var + "_summary.csv")).read(), open(b / (var + "_summary.csv")).read()
+        assert ta == tb, (var, ta[:300], tb[:300])
+        assert ta.count("\n") == 1 + 3 * 4 and ta.startswith("date,signalid,")
+    opts2 = [hmc.estopt(raw, dates, sampleRange=range(1, e + 1), signalRange=range(e - 20, e + 1), signalSave=range(e - 1, e + 1),
+                        endIndex=e, horizons=[12], D=3, burnin=30, Nrun=60, signalburnin=5, signalNrun=23, noiseSamples=4, noise=0.3,
+                        series="t") for e in (150, 201, 177)]
+    none, extra2 = hmc.estimatesignalswindows(opts2, keep_draws=False, summaries=True)
+    assert none is None and np.array_equal(extra2["sample_summary"], extra["sample_summary"])
