@@ -59,12 +59,13 @@ def test_random_shapes_against_oracle(hmclib, oracle, seed, monkeypatch):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("HMCG_FUZZ_N", "96")) // 3))
 def test_random_signal_runs_against_oracle(hmclib, oracle, seed):
     """The same for the signal Monte-Carlo path (estimatesignals!, sigLen = 0): random signal tails, save ranges, noise
-    levels, kappa and numbers of chained noise samples, K = 2..4 across the steps-per-thread variants."""
+    levels, kappa and numbers of chained noise samples, K = 2..8 across the steps-per-thread variants of the register-resident
+    kernel and, for K >= 5 and one case in seven with longer windows, the SIG form of the LDS-resident one."""
     from test_gpu_parity import check_signals_against_oracle
     rng = np.random.default_rng(5000 + seed)
-    K = int(rng.integers(2, 5))
+    K = int(rng.integers(2, 9))                          # K >= 5 (and longer K <= 4 windows): the SIG form of the LDS-resident kernel
     W = int(rng.integers(1, 4))
-    top = [1000, 2040, 1000][K - 2]                      # signal variants: K=2 L<=4, K=3 L<=8, K=4 L<=4
+    top = [1000, 2040, 1000, 700, 700, 600, 600][K - 2] if seed % 7 else [2600, 4500, 2600, 1500, 1500, 1200, 1200][K - 2]
     lens = [int(rng.integers(8, top + 1)) for _ in range(W)]
     Y, Tw, fut = synth.generate_panel(W, max(lens), K, ragged=lens, window_base=seed)
     sig = np.zeros((W, 2), dtype=np.int32)
