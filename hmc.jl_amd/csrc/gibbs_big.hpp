@@ -137,7 +137,6 @@ template <class T> struct StepPtr<true, T> { using type = __attribute__((address
 template <int K, int NT, bool SM = false, bool STREAM = false, bool SIG = false>
 __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams p, const int L)
 {
-    static_assert(!(SIG && SM), "signal path: no smoothing pass on this kernel");
     static_assert(K >= 2 && K <= 8, "4-bit map entries: K <= 8 (K <= 4 normally runs on the register-resident kernel; this one\n"
                                     "also serves small K when the window is too long for it)");
     constexpr int NW = NT / 64;
@@ -834,7 +833,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
             for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
         double N[KK];
-        const bool kept_sweep = sweep >= p.burnin_s;              // one sample per launch on this path
+        const bool kept_sweep = SIG ? kept_index(p, sweep) >= 0 : sweep >= p.burnin_s;     // (without the signal path a launch is one sample)
         const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr);
         {
             // Q <- Q * (A diag(f_t)), in place, four rows at a time: row r of the product needs row r of Q only, so once a

@@ -283,7 +283,6 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
         }
     }
     const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
-    if (use_sig && use_smooth && cfg->K >= 5) { set_err("signal path with smoothed-probability means: K <= 4 only"); return HMCG_E_UNSUPPORTED; }
     if (cfg->sweep_base > n_samples * (cfg->burnin + cfg->nrun)) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).
@@ -295,9 +294,9 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     Plan pl;
     pl.use_sig = use_sig; pl.use_smooth = use_smooth;
     if (cfg->K < 5) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
-    if (!pl.v && !(use_sig && use_smooth)) {           // large K, or a window too long for the register-resident variants
-        const BigVariant* tab = use_sig ? g_big_sig_variants : (use_smooth ? g_big_smooth_variants : g_big_variants);
-        const int ntab = use_sig ? g_n_big_sig_variants : (use_smooth ? g_n_big_smooth_variants : g_n_big_variants);
+    if (!pl.v) {                                       // large K, or a window too long for the register-resident variants
+        const BigVariant* tab = use_sig ? (use_smooth ? g_big_sigsmooth_variants : g_big_sig_variants) : (use_smooth ? g_big_smooth_variants : g_big_variants);
+        const int ntab = use_sig ? (use_smooth ? g_n_big_sigsmooth_variants : g_n_big_sig_variants) : (use_smooth ? g_n_big_smooth_variants : g_n_big_variants);
         for (int i = 0; i < ntab; ++i) if (tab[i].K == cfg->K) pl.bv = &tab[i];
         if (pl.bv) {
             pl.bigL = (maxT + pl.bv->NT - 1) / pl.bv->NT;
@@ -309,11 +308,11 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
             else if (pl.dyn + stat > 160 * 1024 || getenv("HMCG_FORCE_STREAM")) {
                 // too long for the LDS: the same kernel with its per-step arrays in an HBM scratch (HMCG_FORCE_STREAM: tests)
                 pl.bv = nullptr;
-                if (!use_smooth) {
-                    const BigVariant* stab = use_sig ? g_big_sig_stream_variants : g_big_stream_variants;
-                    const int nstab = use_sig ? g_n_big_sig_stream_variants : g_n_big_stream_variants;
-                    for (int i = 0; i < nstab; ++i) if (stab[i].K == cfg->K) pl.bv = &stab[i];
-                }
+                const BigVariant* stab = use_sig ? (use_smooth ? g_big_sigsmooth_stream_variants : g_big_sig_stream_variants)
+                                                 : (use_smooth ? g_big_smooth_stream_variants : g_big_stream_variants);
+                const int nstab = use_sig ? (use_smooth ? g_n_big_sigsmooth_stream_variants : g_n_big_sig_stream_variants)
+                                          : (use_smooth ? g_n_big_smooth_stream_variants : g_n_big_stream_variants);
+                for (int i = 0; i < nstab; ++i) if (stab[i].K == cfg->K) pl.bv = &stab[i];
                 pl.stream = pl.bv != nullptr;
                 pl.dyn = 16;
             }

@@ -32,8 +32,10 @@ struct BigVariant {
     BigKernelFn fn;
 };
 // LDS-resident kernels (gibbs_big.hpp): large K, or windows too long for the register-resident variants
-extern const BigVariant g_big_variants[], g_big_smooth_variants[], g_big_stream_variants[], g_big_sig_variants[], g_big_sig_stream_variants[];
-extern const int g_n_big_variants, g_n_big_smooth_variants, g_n_big_stream_variants, g_n_big_sig_variants, g_n_big_sig_stream_variants;
+extern const BigVariant g_big_variants[], g_big_smooth_variants[], g_big_stream_variants[], g_big_sig_variants[], g_big_sig_stream_variants[],
+    g_big_sigsmooth_variants[], g_big_smooth_stream_variants[], g_big_sigsmooth_stream_variants[];
+extern const int g_n_big_variants, g_n_big_smooth_variants, g_n_big_stream_variants, g_n_big_sig_variants, g_n_big_sig_stream_variants,
+    g_n_big_sigsmooth_variants, g_n_big_smooth_stream_variants, g_n_big_sigsmooth_stream_variants;
 
 #define HMCG_V(K_, L_, NT_, SIG_, SM_, NH_, OCC_, PS_, PB_) \
     { K_, L_, NT_, hmcg::gibbs_sweeps_kernel<K_, L_, NT_, SIG_, SM_, NH_, OCC_>, SIG_, SM_, NH_, OCC_, PS_, PB_ }

@@ -299,11 +299,11 @@ def test_status_flags(hmclib, oracle):
     assert close(gu["mu"][0].T, o["mu"]) < TOL and close(gu["pif_final"][0], o["pif_final"]) < TOL
     assert np.isfinite(gu["mu"][0]).all() and np.isfinite(gu["pif_final"][0]).all()
     # windows beyond the LDS are no longer refused (they stream through HBM: test_windows_beyond_the_lds_stream_through_hbm);
-    # what still has no kernel: more than HMCG_MAXK states, and the smoothing pass on a window beyond the LDS
+    # what still has no kernel: more than HMCG_MAXK states, and a thread count the LDS-resident kernel does not offer
     with pytest.raises(_lib.HmcgError):
         _lib.estimate_batch_host(np.zeros((1, 100)), [100], 9, 1, 1)
     with pytest.raises(_lib.HmcgError, match="no kernel"):
-        _lib.estimate_batch_host(np.zeros((1, 20000)), [20000], 3, 1, 1, want_smooth=True)
+        _lib.estimate_batch_host(np.zeros((1, 20000)), [20000], 3, 1, 1, threads_per_window=512)
 
 
 def test_sharding_reproduces_unsharded_rows(hmclib):

@@ -166,3 +166,43 @@ def test_smoothed_and_filtered_means_on_the_signal_path(hmclib, oracle, K, L):
         assert np.max(np.abs(g["pi_smooth_mean"][w, :T] - o["pi_smooth"].mean(axis=0))) < TOL
         assert np.max(np.abs(g["pi_filter_mean"][w, :T] - o["pi_filter_mean"])) < TOL
         assert np.max(np.abs(g["pi_smooth_mean"][w, :T].sum(axis=1) - 1)) < 1e-12
+
+
+@pytest.mark.parametrize("K,T,stream", [(8, 700, False), (5, 300, False), (6, 1100, True), (3, 2600, False), (4, 2400, True), (3, 9000, True)])
+def test_smoothed_means_on_the_signal_path_lds_resident_kernel(hmclib, oracle, monkeypatch, K, T, stream):
+    """The same for K >= 5 and for longer K <= 4 windows: the smoothing pass of the LDS-resident kernel together with its
+    signal path, LDS-resident and HBM-streaming forms (T = 9000 is beyond the LDS by itself).  The last two refusals of the
+    hot path (`signal path with smoothed-probability means: K <= 4 only`, smoothing beyond the LDS) are gone."""
+    if stream and T < 7000:
+        monkeypatch.setenv("HMCG_FORCE_STREAM", "1")
+    lens = [T, T - 77]
+    Y, Tw, fut = synth.generate_panel(2, T, K, ragged=lens)
+    sig = np.stack([Tw - np.array([30, 1]), Tw], axis=1).astype(np.int32)
+    ssig = np.array([0.4, 0.9])
+    burnin, nrun, ns = 2, 3, 2
+    g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), fut[:, 11:12], want_state=True, sig_range=sig, save_range=sig,
+                                 sigma_signal=ssig, kappa=0.6, n_samples=ns, alpha=2.0, nu=2.0, want_smooth=True, want_filter_mean=True)
+    L = (T + 255) // 256
+    assert g["steps_per_thread"] == L and g["helper_waves"] == 0 and (g["lds_bytes"] < 21 * 256 * L) == stream
+    for w in range(2):
+        Tn = int(Tw[w])
+        o = oracle.estimate_signals(Y[w, :Tn], K, burnin, nrun, ns, sig=tuple(sig[w]), kappa=0.6, alpha=2.0, nu=2.0,
+                                    sigma_signal=float(ssig[w]), save=tuple(sig[w]), yreal=fut[w, 11:12], window_id=w,
+                                    want_smooth=True, want_filter_mean=True)
+        assert g["status"][w] == o["status"] == 0
+        assert np.array_equal(g["x_final"][w, :Tn], o["x_final"])
+        assert close(g["mu"][w].T, o["mu"]) < TOL and close(g["fcast"][w].T, o["fcast"]) < TOL
+        assert np.max(np.abs(g["pi_smooth_mean"][w, :Tn] - o["pi_smooth"].mean(axis=0))) < TOL
+        assert np.max(np.abs(g["pi_filter_mean"][w, :Tn] - o["pi_filter_mean"])) < TOL
+
+
+@pytest.mark.parametrize("K,T", [(3, 9000), (8, 7000), (2, 12000)])
+def test_smoothed_means_beyond_the_lds(hmclib, oracle, K, T):
+    """extras.pi_smooth_mean / pi_filter_mean on windows longer than a CU's LDS holds: the smoothing variant of the HBM-streaming form."""
+    Y, Tw, fut = synth.generate_panel(1, T, K)
+    g = _lib.estimate_batch_host(Y, Tw, K, 1, 3, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
+    o = oracle.estimate_window(Y[0], K, 1, 3, (12,), fut[0, 11:12], window_id=0, want_smooth=True)
+    assert g["status"][0] == o["status"] == 0 and g["lds_bytes"] < 32 * 1024
+    assert np.array_equal(g["x_final"][0], o["x_final"])
+    assert np.max(np.abs(g["pi_smooth_mean"][0] - o["pi_smooth"].mean(axis=0))) < TOL
+    assert close(g["mu"][0].T, o["mu"]) < TOL and close(g["pif_final"][0], o["pif_final"]) < TOL
