@@ -29,3 +29,30 @@ def test_bench_two_ranks_on_the_shared_gpu(hmclib):
     # whole-job aggregate over both ranks: 2 x 256 windows x 1000 draws x 2 steps in the MAX-over-ranks time
     assert abs(rec["value"] - 2 * 256 * 1000 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-9
     assert rec["value"] > 1e6 and "extra" not in rec and "cpu_baseline" not in rec
+
+
+@pytest.mark.timeout(300)
+def test_bench_line_contract_on_one_gpu(hmclib):
+    """`python bench.py --steps 3 --warmup 1` prints ONE JSON line with the contract's keys, the HBM-model roofline (live HIP-event
+    kernel time), the VALU-issue roofline and internally consistent numbers (the driver checks the same things from outside)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
+                       capture_output=True, text=True, timeout=240, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 256 * 1000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["achieved"] - 58160 * 256 * 1000 / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-9
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert rf["kernel"].startswith("hmcg::gibbs_sweeps_kernel<3,4,256,false,false,4,2>") and rf["traffic"] is not None
+    assert rf["measured_hbm_GBps"] < 0.01 * rf["model_GBps"]                  # the chain never leaves the chip
+    ra = d["roofline_alu"]
+    assert ra["bound"] == "valu_issue" and 0.3 < ra["frac"] < 1.0 and 2000 < ra["in_kernel_clock_mhz"] <= 2400
+    assert 20e6 < d["value"] < 200e6
