@@ -47,7 +47,7 @@ class Extras(C.Structure):
                 ("sig_range", C.c_void_p), ("save_range", C.c_void_p), ("sigma_signal", C.c_void_p),
                 ("sigvals", C.c_void_p), ("nsave_ld", C.c_int32), ("reserved2", C.c_int32),
                 ("end_pos", C.c_void_p), ("pi_smooth_mean", C.c_void_p), ("pi_filter_mean", C.c_void_p),
-                ("corr", C.c_void_p), ("sample_summary", C.c_void_p)]
+                ("corr", C.c_void_p), ("pi_smooth_draws", C.c_void_p), ("sample_summary", C.c_void_p)]
 
 
 class Timing(C.Structure):
@@ -155,7 +155,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
                         resume_state=None, sweep_base=0, window_ids=None, sweep_count=0,
                         sig_range=None, save_range=None, sigma_signal=None, kappa=0.0, n_samples=0, want_smooth=False,
                         end_pos=None, blend_mask=0, want_filter_mean=False, devices=None, out=None, want_corr=False,
-                        want_sample_summary=False, resume_sample_summary=None, nan_fill=True):
+                        want_sample_summary=False, resume_sample_summary=None, nan_fill=True, want_smooth_draws=False):
     """hmcg_estimate_batch over host (numpy) buffers.  Returns dict of arrays in the
     C-ABI layouts (window slowest): mu/sig2/pi_end (W,K,nrun), A (W,K,K,nrun) with
     A[w, j, i, d] = draw d of A[i,j], fcast (W,2H,nrun), summary (W,NS), status (W,).
@@ -219,6 +219,9 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
         out["sample_summary"] = (np.zeros((W, max(int(n_samples), 1), NS)) if resume_sample_summary is None else
                                  np.ascontiguousarray(resume_sample_summary, dtype=np.float64).reshape(W, max(int(n_samples), 1), NS).copy())
         ex.sample_summary = out["sample_summary"].ctypes.data
+    if want_smooth_draws:                      # samples.pib[Nrun, N, D] of every window: (W, K, ldY, nd), draw index fastest
+        out["pi_smooth_draws"] = np.zeros((W, K, ldY, nd))
+        ex.pi_smooth_draws = out["pi_smooth_draws"].ctypes.data
     if want_smooth:
         out["pi_smooth_mean"] = np.zeros((W, ldY, K))
         ex.pi_smooth_mean = out["pi_smooth_mean"].ctypes.data
@@ -267,7 +270,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     # plausible-looking zero (the reference would have thrown, src/Hmc.jl:435)
     skipped = (out["status"] & ST_SKIPPED) != 0
     if skipped.any() and nan_fill:
-        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final", "corr", "sample_summary"):
+        for name in keep + ("summary", "sigvals", "pi_smooth_mean", "pi_filter_mean", "pif_final", "corr", "sample_summary", "pi_smooth_draws"):
             if name in out:
                 out[name][skipped] = np.nan
     out["kernel_ms"] = tm.kernel_ms

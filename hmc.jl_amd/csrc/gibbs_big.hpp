@@ -834,7 +834,9 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
         double N[KK];
         const bool kept_sweep = SIG ? kept_index(p, sweep) >= 0 : sweep >= p.burnin_s;     // (without the signal path a launch is one sample)
-        const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr);
+        const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr || p.pi_smooth_draws != nullptr);
+        const int dk = SIG ? kept_index(p, sweep) : sweep - p.burnin_s;      // kept-draw index (meaningful when kept_sweep)
+        (void)dk;
         {
             // Q <- Q * (A diag(f_t)), in place, four rows at a time: row r of the product needs row r of Q only, so once a
             // block of rows has all its columns it replaces the block it came from -- one matrix and half a matrix live
@@ -1106,6 +1108,8 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
                             for (int s = 0; s < K; ++s) { gq = (order[q] == s) ? g[s] : gq; fq = (order[q] == s) ? pfv[s] : fq; }
                             if (p.pi_smooth_mean) p.pi_smooth_mean[((size_t)w * p.ldY + t) * K + q] += gq * inv;   // sorted labels (:513)
+                            if (p.pi_smooth_draws)                                                                  // samples.pib[d, t, q] (:558)
+                                p.pi_smooth_draws[(size_t)p.nd_ld * ((size_t)q * p.ldY + t + (size_t)K * p.ldY * w) + (dk - p.draw_off)] = gq * inv;
                             if (p.pi_filter_mean) p.pi_filter_mean[((size_t)w * p.ldY + t) * K + q] += fq;         // sorted pif[t,:] (:512)
                         }
                         double fv[K], fb[K], nb[K];

@@ -82,6 +82,9 @@ struct KernelParams {
     double* pi_smooth_mean;
     // the same running sum for the FILTERED probabilities pif[t,:] (sorted labels), [W][ldY][K]; SMOOTH variants
     double* pi_filter_mean;
+    // every kept draw's smoothed probabilities (sorted labels), [W][K][ldY][nd_ld] with the draw index fastest = the
+    // reference's samples.pib[Nrun, N, D] (:552,558); this launch's draws at column d - draw_off, as the other outputs
+    double* pi_smooth_draws;
     // signal path: per noise sample the mean over its nrun_s kept draws of the rounded outputs, [W][n_samples][NS] (one row
     // of upstream's runaggregate over a signal run, src/Hmc.jl:1025-1057); the raw running sums while a sample is incomplete
     double* sample_summary;
@@ -1896,7 +1899,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
                 b[r] = acc;
             }
             rescale_pow2<K>(b);
-            const bool kept = SIG ? kept_index(p, sweep) >= 0 : sweep >= p.burnin_s;
+            const int dk = SIG ? kept_index(p, sweep) : (sweep >= p.burnin_s ? sweep - p.burnin_s : -1);     // kept-draw index
+            const bool kept = dk >= 0;
 #pragma unroll
             for (int l = L - 1; l >= 0; --l) {
                 if (t0 + l < T) {
@@ -1911,6 +1915,8 @@ void gibbs_sweeps_kernel(const KernelParams p)
 #pragma unroll
                             for (int s = 0; s < K; ++s) gq = (order[q] == s) ? g[s] : gq;
                             sm_acc[l][q] = fma(gq, inv, sm_acc[l][q]);      // sorted labels (:513)
+                            if (p.pi_smooth_draws)                          // samples.pib[d, t, q] itself (:558)
+                                p.pi_smooth_draws[(size_t)p.nd_ld * ((size_t)q * p.ldY + (t0 + l) + (size_t)K * p.ldY * w) + (dk - p.draw_off)] = gq * inv;
                             double fq = 0.0;
 #pragma unroll
                             for (int s = 0; s < K; ++s) fq = (order[q] == s) ? pf[l][s] : fq;

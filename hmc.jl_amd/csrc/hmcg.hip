@@ -282,7 +282,7 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
             return HMCG_E_BADARG;
         }
     }
-    const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr);
+    const bool use_smooth = ex && (ex->pi_smooth_mean != nullptr || ex->pi_filter_mean != nullptr || ex->pi_smooth_draws != nullptr);
     if (cfg->sweep_base > n_samples * (cfg->burnin + cfg->nrun)) { set_err("sweep_base beyond the run"); return HMCG_E_BADARG; }
     // Flavour: helper waves pay off while every window has a CU to itself; with more windows than CUs the capped
     // plain variant lets two windows share a CU instead (a helped block takes the whole register file).
@@ -345,7 +345,7 @@ hmcg::KernelParams base_params(const hmcg_config* cfg, int W, const double* dY, 
     p.nu = cfg->nu > 0.0 ? cfg->nu : 1.0;
     p.status = dstatus;
     if (dex) {
-        p.pi_smooth_mean = dex->pi_smooth_mean; p.pi_filter_mean = dex->pi_filter_mean;
+        p.pi_smooth_mean = dex->pi_smooth_mean; p.pi_filter_mean = dex->pi_filter_mean; p.pi_smooth_draws = dex->pi_smooth_draws;
         p.sig_range = dex->sig_range; p.save_range = dex->save_range; p.sigma_signal = dex->sigma_signal;
         p.sigvals = dex->sigvals; p.nsave_ld = dex->nsave_ld;
         p.x_init = dex->x_init; p.x_final = dex->x_final; p.pif_final = dex->pif_final; p.xstate = dex->xstate;
@@ -547,12 +547,14 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
 
     // per-draw output columns of one window, in the order they sit in a chunk buffer
     struct Col { double* host; size_t ncol; size_t off; };
-    Col cols[5] = { {h.mu, K, 0}, {h.sig2, K, 0}, {h.A, K * K, 0}, {h.pi_end, K, 0}, {h.fcast, 2 * H, 0} };
+    // (the sixth group, extras.pi_smooth_draws, is K * ldY columns wide: samples.pib[Nrun, N, D] of every window)
+    Col cols[6] = { {h.mu, K, 0}, {h.sig2, K, 0}, {h.A, K * K, 0}, {h.pi_end, K, 0}, {h.fcast, 2 * H, 0},
+                    {ex ? ex->pi_smooth_draws : nullptr, K * ld, 0} };
     size_t ncols = 0;
     const bool want_corr = ex && ex->corr;          // needs every draw column on the device, wanted by the caller or not
     bool copy_out = false;
     for (Col& cc : cols) {
-        if (!(cc.host || want_corr) || nd_total == 0) cc.ncol = 0;
+        if (!(cc.host || (want_corr && &cc != &cols[5])) || nd_total == 0) cc.ncol = 0;
         if (cc.host && cc.ncol) copy_out = true;
         cc.off = ncols; ncols += cc.ncol;
     }
@@ -734,9 +736,13 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
                 const size_t g = row(i);
                 for (const Col& cc : cols) {
                     if (!cc.host) continue;
-                    for (size_t q = 0; q < cc.ncol; ++q)
-                        memcpy(cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0,
-                               src + ndc * (cc.off * N + q + cc.ncol * (size_t)i), 8 * ndc);
+                    const bool per_step = &cc == &cols[5];          // pi_smooth_draws: column = k * ldY + t; the kernel writes t < T[w] only
+                    const size_t Tg = per_step ? (size_t)std::max(0, std::min((int)ld, (int)h.T[g])) : 0;
+                    for (size_t q = 0; q < cc.ncol; ++q) {
+                        double* dst = cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0;
+                        if (per_step && (q % ld) >= Tg) memset(dst, 0, 8 * ndc);              // beyond the window: reads zero
+                        else memcpy(dst, src + ndc * (cc.off * N + q + cc.ncol * (size_t)i), 8 * ndc);
+                    }
                 }
             }
         };
@@ -770,6 +776,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             p.A = cols[2].ncol ? cb + ndc * cols[2].off * N : nullptr;
             p.pi_end = cols[3].ncol ? cb + ndc * cols[3].off * N : nullptr;
             p.fcast = cols[4].ncol ? cb + ndc * cols[4].off * N : nullptr;
+            p.pi_smooth_draws = cols[5].ncol ? cb + ndc * cols[5].off * N : nullptr;
             // (a skipped window writes nothing into its block: its rows of the caller's arrays are zeroed at the end of the
             //  call, once the status words are back -- no memset node per chunk on the stream)
         }

@@ -181,6 +181,9 @@ def _unpack(res, w, nrun, K, H, obsdate):
 def estimatemodel(opt, device=0, smooth=False, window_id=0):
     """Hmc.estimatemodel(opt) (src/Hmc.jl:850-865) on the GPU.
 
+    smooth="draws" returns the reference's full samples.πb[Nrun, N, D] (every kept draw's smoothed probabilities,
+    backwardupdate_P!, :442-457, stored per draw :558) -- 8 N D bytes per draw -- besides πb_mean / πf_mean.
+
     smooth=True additionally runs the full backward pass (backwardupdate_P!, :442-457) every sweep and
     returns, as `samples.πb_mean` (N, D), the mean over the kept draws of the smoothed probabilities
     `samples.πb[:, t, :]` -- what smoothStates/forecastinsample average upstream (:649-654, :696).
@@ -200,9 +203,12 @@ def estimatemodel(opt, device=0, smooth=False, window_id=0):
         kw = dict(sig_range=[sig], save_range=[sv], sigma_signal=[0.0], kappa=1.0, n_samples=1)
     res = _lib.estimate_batch_host(Y[None, :], [len(Y)], opt.D, opt.burnin, opt.Nrun, tuple(opt.horizons),
                                    _yreal_row(opt.rawdata, opt.endIndex, opt.horizons)[None, :], seed=opt.seed,
-                                   device=device, want_smooth=smooth, want_filter_mean=smooth, window_ids=[window_id], **kw)
+                                   device=device, want_smooth=bool(smooth), want_filter_mean=bool(smooth), window_ids=[window_id],
+                                   want_smooth_draws=(smooth == "draws"), **kw)
     _check_status(res["status"], "estimatemodel")
     s = _unpack(res, 0, opt.Nrun, opt.D, len(opt.horizons), enddate(opt))
+    if smooth == "draws":
+        s.πb = np.ascontiguousarray(np.transpose(res["pi_smooth_draws"][0, :, :len(Y), :], (2, 1, 0)))     # (Nrun, N, D), as upstream
     if smooth:
         s.πb_mean = res["pi_smooth_mean"][0, :len(Y)]
         s.πf_mean = res["pi_filter_mean"][0, :len(Y)]      # draw-averaged filtered probabilities (sorted labels)

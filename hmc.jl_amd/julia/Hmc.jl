@@ -75,12 +75,13 @@ struct hmcg_extras
     pi_smooth_mean::Ptr{Float64}
     pi_filter_mean::Ptr{Float64}
     corr::Ptr{Float64}
+    pi_smooth_draws::Ptr{Float64}     # [W][K][ldY][nd] = (Nrun, N, D, W): samples.pib of every kept draw (src/Hmc.jl:552,558)
     sample_summary::Ptr{Float64}      # [W][n_samples][3K+K^2+2H]: runaggregate's (date, signalid) rows of a signal run (hmcg.h)
 end
 const HMCG_MAXTAIL = 256
 const HMCG_MAXDEV = 16
 
-struct hmcg_timing                    # include/hmcg.h (ABI 105)
+struct hmcg_timing                    # include/hmcg.h (ABI 106)
     kernel_ms::Float64
     launches::Int32
     threads_per_window::Int32
@@ -203,7 +204,7 @@ function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothin
     wids = window_ids === nothing ? UInt32[] : Vector{UInt32}(window_ids)
     ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
                          isempty(wids) ? Ptr{UInt32}(C_NULL) : pointer(wids), C_NULL, C_NULL, C_NULL, C_NULL, Int32(0), Int32(0),
-                         C_NULL, C_NULL, C_NULL, corr ? pointer(ρ) : Ptr{Float64}(C_NULL), C_NULL))
+                         C_NULL, C_NULL, C_NULL, corr ? pointer(ρ) : Ptr{Float64}(C_NULL), C_NULL, C_NULL))
     yr = H > 0 ? pointer(yreal) : Ptr{Float64}(C_NULL)
     rc = GC.@preserve Y Ts yreal μ σ A πe fc summary status wids ρ begin
         if devices === nothing
@@ -266,7 +267,7 @@ function _signal_call(opt::estopt, burnin, nrun, n_samples, σsignal, κ, α, ν
     rc = GC.@preserve Y T yreal μ σ A πe fc st sig sv ssig sigvals ep begin
         ex = Ref(hmcg_extras(Int32(sizeof(hmcg_extras)), Int32(0), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
                              pointer(sig), pointer(sv), pointer(ssig), pointer(sigvals), Int32(max(nsave, 1)), Int32(0),
-                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL, C_NULL, C_NULL, C_NULL))
+                             endpos >= 0 ? pointer(ep) : Ptr{Int32}(C_NULL), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
         ccall((:hmcg_estimate_batch, LIBHMCG), Cint,
               (Ref{hmcg_config}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ref{hmcg_extras}, Ptr{Cvoid}),

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 105
+#define HMCG_VERSION 106
 #define HMCG_MAXH 8
 #define HMCG_MAXTAIL 256        /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
@@ -155,6 +155,11 @@ typedef struct hmcg_extras {
                                    with H >= 1; the host entries accept NULL for them and then keep the draws on the device),
                                    n_samples <= 1 and the whole run in one call (no sweep_base / sweep_count / RESUME).  A
                                    constant column gives NaN, as Statistics.cor does */
+    double* pi_smooth_draws;    /* [W][K][ldY][nd] = Julia (Nrun, N, D, W), optional: EVERY kept draw's smoothed probabilities in sorted
+                                   labels -- the reference's samples.pib[Nrun, N, D] itself (gibbssample!, src/Hmc.jl:552,558), of
+                                   which its live outputs only read [:, end, :] (= pi_end).  8 K T bytes per draw and window (24 KB at
+                                   K = 3, T = 1000): the host entries stream it chunk by chunk like the other per-draw outputs.  Runs the
+                                   smoothing variants, as pi_smooth_mean does */
     double* sample_summary;     /* [W][n_samples][3K+K*K+2H] optional, signal path: for every noise sample the mean over its
                                    nrun kept draws of the 5-digit-rounded outputs, columns as in `summary` -- one row of the
                                    `*_summary.csv` files upstream's runaggregate (src/Hmc.jl:1025-1057, grouped by date and

@@ -202,3 +202,18 @@ def test_signal_summaries_from_the_device_equal_the_file_route(hmclib, tmp_path)
                         series="t") for e in (150, 201, 177)]
     none, extra2 = hmc.estimatesignalswindows(opts2, keep_draws=False, summaries=True)
     assert none is None and np.array_equal(extra2["sample_summary"], extra["sample_summary"])
+
+
+def test_estimatemodel_returns_the_full_pib_on_request(hmclib, oracle):
+    """samples.πb[Nrun, N, D] as upstream's estimatemodel returns it (src/Hmc.jl:864): smooth="draws"."""
+    T = 300
+    Y, _ = synth.generate_window(T, 3, seed=77)
+    dates = [hmc.makedate(120 + i) for i in range(T)]
+    opt = hmc.estopt(Y, dates, sampleRange=range(1, T - 12 + 1), endIndex=T - 12, horizons=[12], D=3, burnin=5, Nrun=9, series="t")
+    s = hmc.estimatemodel(opt, smooth="draws")
+    N = T - 12
+    assert s.πb.shape == (9, N, 3) and np.max(np.abs(s.πb.sum(axis=2) - 1)) < 1e-12
+    o = oracle.estimate_window(Y[:N], 3, 5, 9, (12,), [Y[N + 11]], seed=opt.seed, window_id=0, want_smooth=True)
+    assert np.max(np.abs(s.πb - o["pi_smooth"])) < 1e-9 and np.max(np.abs(s.πb.mean(axis=0) - s.πb_mean)) < 1e-12
+    f, e = hmc.forecast(s.μ[0], s.A[0], s.πb[0, -1, :], 12, Y[N + 11])             # :860-862 reads πb[idx, end, :]
+    assert abs(f - s.forecasts[0, 0]) < 1e-9 and abs(e - s.forecasts[0, 1]) < 1e-9

@@ -583,3 +583,28 @@ def test_signals_past_the_end_date_on_the_lds_resident_kernel(hmclib, oracle, mo
     s = _lib.estimate_batch_host(Y, Tw, K, 4, 10, horizons, yreal, want_state=True, **kw)
     for k in ("mu", "sig2", "A", "pi_end", "fcast", "summary", "sample_summary", "sigvals", "x_final", "pif_final"):
         assert np.array_equal(g[k], s[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("K,lens", [(3, [1000, 257, 64]), (2, [300, 2]), (4, [700, 100]), (8, [900, 300]), (5, [600, 65]), (3, [5000]), (3, [8000])])
+def test_per_draw_smoothed_probabilities(hmclib, oracle, monkeypatch, K, lens):
+    """extras.pi_smooth_draws: the reference's samples.pib[Nrun, N, D] itself (gibbssample!, src/Hmc.jl:552,558) -- every kept
+    draw's smoothed probabilities in sorted labels, [W][K][ldY][nd] = Julia (Nrun, N, D, W) -- from the register-resident SMOOTH
+    variants, the LDS-resident smoothing kernel and its HBM-streaming form, against the oracle's literal Pb recursion;
+    streamed by the host entry in chunks (a chunk size that does not divide the run), equal to the single launch."""
+    Y, Tw, fut = synth.generate_panel(len(lens), max(lens), K, ragged=lens)
+    burnin, nrun = 2, 7
+    args = (Y, Tw, K, burnin, nrun, (12,), fut[:, 11:12])
+    g = _lib.estimate_batch_host(*args, want_state=True, want_smooth_draws=True, want_smooth=True)
+    for w in range(len(lens)):
+        T = int(Tw[w])
+        o = oracle.estimate_window(Y[w, :T], K, burnin, nrun, (12,), fut[w, 11:12], window_id=w, want_smooth=True)
+        assert g["status"][w] == o["status"] == 0 and np.array_equal(g["x_final"][w, :T], o["x_final"])
+        got = np.transpose(g["pi_smooth_draws"][w, :, :T, :], (2, 1, 0))              # (nrun, T, K)
+        assert np.max(np.abs(got - o["pi_smooth"])) < TOL
+        assert np.max(np.abs(got.sum(axis=2) - 1)) < 1e-12
+        assert np.max(np.abs(got[:, -1, :] - g["pi_end"][w].T)) < 1e-12              # pib[:, end, :] is what pi_end reports (:448)
+        assert np.max(np.abs(got.mean(axis=0) - g["pi_smooth_mean"][w, :T])) < 1e-12
+        assert not g["pi_smooth_draws"][w, :, T:, :].any()                            # beyond the window: untouched zeros
+    monkeypatch.setenv("HMCG_CHUNK_DRAWS", "3")
+    c = _lib.estimate_batch_host(*args, want_state=True, want_smooth_draws=True)
+    assert c["launches"] >= 3 and np.array_equal(c["pi_smooth_draws"], g["pi_smooth_draws"]) and np.array_equal(c["mu"], g["mu"])
