@@ -293,7 +293,8 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     if (const char* fenv = getenv("HMCG_FLAVOUR")) force = !strcmp(fenv, "h") ? H : (!strcmp(fenv, "p2") ? P2 : P1);
     Plan pl;
     pl.use_sig = use_sig; pl.use_smooth = use_smooth;
-    if (cfg->K < 5) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
+    // HMCG_FORCE_BIG=1 (diagnostics): the LDS-resident kernel also where a register-resident variant exists
+    if (cfg->K < 5 && !getenv("HMCG_FORCE_BIG")) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
     if (!pl.v) {                                       // large K, or a window too long for the register-resident variants
         const BigVariant* tab = use_sig ? (use_smooth ? g_big_sigsmooth_variants : g_big_sig_variants) : (use_smooth ? g_big_smooth_variants : g_big_variants);
         const int ntab = use_sig ? (use_smooth ? g_n_big_sigsmooth_variants : g_n_big_sig_variants) : (use_smooth ? g_n_big_smooth_variants : g_n_big_variants);
