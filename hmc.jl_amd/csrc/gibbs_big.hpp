@@ -533,50 +533,46 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     };
 
     // ---- sufficient statistics of the chain state in xs[] -------------------------------------
-    auto publish_stats = [&]() __attribute__((always_inline)) {
+    // The statistics are accumulated per thread over its L steps, LAST step first -- the order of the backward pass's apply
+    // loop, which takes them along at the end of every sweep (below); the stand-alone form (prologue, resumed launches, a new
+    // noise sample) walks the same way, so that a resumed chain adds the same numbers in the same order as an uninterrupted one.
+    struct StatAcc { double d1[K], d2[K], s1[SIG ? K : 1], s2[SIG ? K : 1]; };
+    auto stats_begin = [&](StatAcc& a) __attribute__((always_inline)) {
         for (int e = lane; e < KK; e += 64) sh.cnt[wave][e] = 0;
         if constexpr (SIG) { if (lane < K) sh.cntm[wave][lane] = 0; }
         __builtin_amdgcn_wave_barrier();
-        double d1[K], d2[K], s1[SIG ? K : 1], s2[SIG ? K : 1];
 #pragma unroll
-        for (int i = 0; i < K; ++i) { d1[i] = 0.0; d2[i] = 0.0; }
+        for (int i = 0; i < K; ++i) { a.d1[i] = 0.0; a.d2[i] = 0.0; }
 #pragma unroll
-        for (int i = 0; i < (SIG ? K : 1); ++i) { s1[i] = 0.0; s2[i] = 0.0; }
-        (void)s1; (void)s2;
-        // (software-pipelined: the state two steps ahead, the observation and the pivot one step ahead are in flight while
-        //  a step is accumulated -- as a plain loop every iteration waited for two dependent LDS reads, x then pivot[x])
-        int xc = min((int)xs[t0], K - 1), xn = min((int)xs[t0 + 1], K - 1);
-        double yc = ylds[t0], pc = sh.pivot[xc];
-        for (int l = 0; l < L; ++l) {
-            const int t = t0 + l;
-            const int xnn = min((int)xs[t + 2], K - 1);                  // xs has 8 spare entries behind cap
-            const double yn = ylds[min(t + 1, cap - 1)];
-            const double pn = sh.pivot[xn];
-            if (t < T) {
-                const int xv = xc;
-                const double dl = yc - pc;
-                const bool issig = SIG && t >= sb && t < se;
-                const int xo = issig ? -1 : xv;                    // observation set (src/Hmc.jl:254-258)
+        for (int i = 0; i < (SIG ? K : 1); ++i) { a.s1[i] = 0.0; a.s2[i] = 0.0; }
+    };
+    // step t (< T) in state xv, followed by state xn (counted when t + 1 < T), observation yv, pivot pv of state xv
+    auto stats_step = [&](StatAcc& a, int t, int xv, int xn, double yv, double pv) __attribute__((always_inline)) {
+        const double dl = yv - pv;
+        const bool issig = SIG && t >= sb && t < se;
+        const int xo = issig ? -1 : xv;                    // observation set (src/Hmc.jl:254-258)
 #pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    const double dm = (xo == i) ? dl : 0.0;
-                    d1[i] += dm;
-                    d2[i] = fma(dm, dm, d2[i]);
-                }
-                if constexpr (SIG) {
-                    const int xg = issig ? xv : -1;                // signal set (:268-272)
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        const double dm = (xg == i) ? dl : 0.0;
-                        s1[i] += dm;
-                        s2[i] = fma(dm, dm, s2[i]);
-                    }
-                    if (issig) atomicAdd(&sh.cntm[wave][xv], 1u);
-                }
-                if (t + 1 < T) atomicAdd(&sh.cnt[wave][xv * K + xn], 1u);
-            }
-            xc = xn; xn = xnn; yc = yn; pc = pn;
+        for (int i = 0; i < K; ++i) {
+            const double dm = (xo == i) ? dl : 0.0;
+            a.d1[i] += dm;
+            a.d2[i] = fma(dm, dm, a.d2[i]);
         }
+        if constexpr (SIG) {
+            const int xg = issig ? xv : -1;                // signal set (:268-272)
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const double dm = (xg == i) ? dl : 0.0;
+                a.s1[i] += dm;
+                a.s2[i] = fma(dm, dm, a.s2[i]);
+            }
+            if (issig) atomicAdd(&sh.cntm[wave][xv], 1u);
+        }
+        if (t + 1 < T) atomicAdd(&sh.cnt[wave][xv * K + xn], 1u);
+    };
+    auto stats_finish = [&](StatAcc& a) __attribute__((always_inline)) {
+        double (&d1)[K] = a.d1; double (&d2)[K] = a.d2;
+        double (&s1)[SIG ? K : 1] = a.s1; double (&s2)[SIG ? K : 1] = a.s2;
+        (void)s1; (void)s2;
         double o0, o1, v8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v8[i] = i < K ? d1[i] : 0.0;
@@ -613,6 +609,18 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             }
         }
         if (tid == 0) sh.x_end = x_end;
+    };
+    auto publish_stats = [&]() __attribute__((always_inline)) {            // stand-alone: from xs[], ylds[], sh.pivot[]
+        StatAcc a;
+        stats_begin(a);
+        for (int l = L - 1; l >= 0; --l) {
+            const int t = t0 + l;
+            if (t < T) {
+                const int xv = min((int)xs[t], K - 1), xn = min((int)xs[t + 1], K - 1);          // xs has 8 spare entries behind cap
+                stats_step(a, t, xv, xn, ylds[t], sh.pivot[xv]);
+            }
+        }
+        stats_finish(a);
     };
     // a new noise sample (src/Hmc.jl:892): Yfake = Yreal + N(0,1) * sigma_signal on the signal range (every thread its own
     // steps: the statistics that follow read the same ones); the chain state carries over (:889-895)
@@ -1195,18 +1203,30 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         Hx.hi = __shfl_down(Hm.hi, 1, 64);
         if (lane == 63) Hx = bytemap_identity();
         int sin = (int)(bytemap_compose(Hx, Rw).lo & 0xFFu);               // entry 0 (a constant map below T-1)
+        // apply the maps last step first -- and take the next sweep's sufficient statistics along: the state entering the
+        // chunk is X[t0 + L] itself, so every transition (x_t -> x_{t+1}) is known where x_t is produced, and the pivots of
+        // the one-pass sums are this sweep's means (what sh.pivot becomes below).  One pass over the window instead of two.
+        StatAcc sa;
+        stats_begin(sa);
         uint32_t anext = maps[t0 + L - 1];
+        double ynext = ylds[t0 + L - 1];
         for (int l = L - 1; l >= 0; --l) {
             const int t = t0 + l;
             const uint32_t am = anext;
-            if (l > 0) anext = maps[t - 1];
-            if (t < T) { sin = map_apply(am, sin); xs[t] = (uint8_t)sin; }
+            const double yv = ynext;
+            if (l > 0) { anext = maps[t - 1]; ynext = ylds[t - 1]; }
+            if (t < T) {
+                const int xn = sin;
+                sin = map_apply(am, sin);
+                xs[t] = (uint8_t)sin;
+                stats_step(sa, t, sin, min(xn, K - 1), yv, th.mu[sin]);
+            }
         }
         x_end = xlast;
-        if (tid < K) sh.pivot[tid] = th.mu[tid];                             // pivots of the next one-pass statistics
+        if (tid < K) sh.pivot[tid] = th.mu[tid];                             // pivots of these statistics (checkpoint; stand-alone form)
         STAMP(12);
-        __syncthreads();                                                     // Bf: xs, pivot complete
-        publish_stats();
+        stats_finish(sa);
+        if constexpr (SIG) __syncthreads();                                  // Bf: xs, pivot complete (a new noise sample re-reads them)
         STAMP(13);
     }
 #ifdef HMCG_STAMPS
