@@ -922,20 +922,26 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         STAMP(6);
         // prefix vector rho' * (earlier waves) * (exclusive lane prefix)
         double av[K];
-#pragma unroll
-        for (int s = 0; s < K; ++s) av[s] = th.rho[s];
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        for (int ww = 0; ww < wave_u; ++ww) {
-            double nv[K];
+        {
+            // rho' W_0 ... W_{wave-1} is the same in every lane, and the last wave's three dependent products stand between every
+            // other wave and barrier Bd.  As 64 redundant K x K vector-matrix products each was 64 FMAs behind 32 LDS reads
+            // (~1 k ticks a step); cooperatively -- lane c of every 8-lane group carries entry c, reads column c of the total
+            // (K reads), gets the K entries of the vector by lane shuffles -- a step is K FMAs.  Same sums in the same order.
+            const int c8 = lane & 7, g8 = lane & ~7;
+            const int cc = c8 < K ? c8 : 0;
+            double vc = th.rho[cc];
+            for (int ww = 0; ww < wave_u; ++ww) {
+                double col[K];
 #pragma unroll
-            for (int s = 0; s < K; ++s) {
-                double acc = av[0] * sh.wtot[ww][s];
+                for (int r = 0; r < K; ++r) col[r] = sh.wtot[ww][r * K + cc];
+                double acc = __shfl(vc, g8, 64) * col[0];
 #pragma unroll
-                for (int r = 1; r < K; ++r) acc = fma(av[r], sh.wtot[ww][r * K + s], acc);
-                nv[s] = acc;
+                for (int r = 1; r < K; ++r) acc = fma(__shfl(vc, g8 | r, 64), col[r], acc);
+                vc = acc;
             }
 #pragma unroll
-            for (int s = 0; s < K; ++s) av[s] = nv[s];
+            for (int s = 0; s < K; ++s) av[s] = __shfl(vc, g8 | s, 64);
         }
         {
             double nv[K];
