@@ -38,7 +38,8 @@ class Config(C.Structure):
                 ("horizons", C.c_int32 * HMCG_MAXH), ("seed", C.c_uint64), ("window_base", C.c_uint32),
                 ("device", C.c_int32), ("flags", C.c_int32), ("threads_per_window", C.c_int32),
                 ("sweep_base", C.c_int32), ("sweep_count", C.c_int32), ("alpha", C.c_double), ("nu", C.c_double),
-                ("kappa", C.c_double), ("n_samples", C.c_int32), ("blend_mask", C.c_int32)]
+                ("kappa", C.c_double), ("n_samples", C.c_int32), ("blend_mask", C.c_int32),
+                ("min_T", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class Extras(C.Structure):
@@ -53,7 +54,8 @@ class Extras(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int32), ("threads_per_window", C.c_int32),
                 ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32), ("helper_waves", C.c_int32),
-                ("device", C.c_int32), ("call_ms", C.c_double), ("windows", C.c_int32), ("occupancy", C.c_int32)]
+                ("device", C.c_int32), ("call_ms", C.c_double), ("windows", C.c_int32), ("occupancy", C.c_int32),
+                ("buckets", C.c_int32), ("reserved", C.c_int32)]
 
 
 _LIB = None
@@ -126,7 +128,7 @@ def _check(rc):
 
 def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base=0, device=0, flags=0,
                 threads_per_window=0, sweep_base=0, alpha=0.0, nu=0.0, sweep_count=0, kappa=0.0, n_samples=0,
-                blend_mask=0):
+                blend_mask=0, min_T=0):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.W, cfg.K, cfg.ldY, cfg.max_T = int(W), int(K), int(ldY), int(max_T)
@@ -142,6 +144,7 @@ def make_config(W, K, ldY, max_T, burnin, nrun, horizons, seed=1234, window_base
     cfg.sweep_count = int(sweep_count)
     cfg.kappa, cfg.n_samples = float(kappa), int(n_samples)
     cfg.blend_mask = int(blend_mask)
+    cfg.min_T = int(min_T)
     cfg.alpha, cfg.nu = float(alpha), float(nu)
     return cfg
 
@@ -279,6 +282,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     out["lds_bytes"] = tm.lds_bytes
     out["helper_waves"] = tm.helper_waves
     out["launches"] = tm.launches
+    out["buckets"] = tm.buckets
     out["call_ms"] = max(t.call_ms for t in tms)
     out["per_device"] = [dict(device=t.device, windows=t.windows, kernel_ms=t.kernel_ms, call_ms=t.call_ms, launches=t.launches)
                          for t in tms]

@@ -95,6 +95,10 @@ struct KernelParams {
     // the sweep's uniforms, the state maps and the states, [W][stream_stride] bytes; library-owned
     uint8_t* sscr;
     int64_t stream_stride;
+    // length-bucketed dispatch (hmcg.hip, launch_buckets): this launch runs the windows with t_lo < T[w] <= t_hi only; the
+    // blocks of every other window leave at once (another launch of the same call, with the steps-per-thread variant
+    // that fits them, runs beside this one on its own stream).  One launch for everything: INT32_MIN / INT32_MAX
+    int32_t t_lo, t_hi;
 };
 
 // bytes of one window's slab of KernelParams::sscr for `cap` = NT * L steps (observations | uniforms | maps | states + 8)
@@ -798,13 +802,20 @@ void gibbs_sweeps_kernel(const KernelParams p)
     __shared__ Sh sh;
 
     const int w = blockIdx.x;
+#ifdef HMCG_VECTOR_WAVE                                     // (A/B only: the wave id as a per-lane value, as until round 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#else
+    // the wave id is a SCALAR: everything that depends on it branches (s_cbranch_scc) instead of opening an exec-masked
+    // region -- fewer lane masks parked in SGPRs, fewer join blocks (the places the allocator fault of DESIGN 5a strikes)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const int T = p.T[w];
     const int t0 = tid * L;                                // helper threads: t0 >= NT*L >= T, so they own no step
     const int owner = (T - 1) / L, l_last = (T - 1) % L;   // thread and slot that hold the last time step
     const bool helper = NH > 0 && __builtin_amdgcn_readfirstlane(wave) >= NW;   // wave-uniform
     int st = 0;
 
+    if (T <= p.t_lo || T > p.t_hi) __builtin_amdgcn_endpgm();   // another length bucket's window: this block leaves at once
     if (T < 2 || T > NT * L || T > p.ldY) {   // uniform per block
         if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
         return;

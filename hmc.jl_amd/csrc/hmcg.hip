@@ -43,6 +43,17 @@ void set_err(const char* fmt, ...)
     va_end(ap);
 }
 
+// Diagnostic switches (fault injection, forced kernel forms, chunking overrides, virtual devices, trace) are armed by
+// HMCG_DIAG=1, read ONCE when the library is first used: without it none of them is looked at -- no getenv on the call
+// path, and a stray HMCG_* variable in a production environment changes nothing.  With it they are read per call, so a
+// test process can switch them between calls.
+bool diag_on()
+{
+    static const bool on = [] { const char* e = getenv("HMCG_DIAG"); return e && atoi(e) != 0; }();
+    return on;
+}
+const char* diag_env(const char* name) { return diag_on() ? getenv(name) : nullptr; }
+
 #define HIP_TRY(expr)                                                                  \
     do {                                                                               \
         hipError_t e_ = (expr);                                                        \
@@ -89,6 +100,7 @@ struct Layout {
 };
 
 constexpr int RING = 3;            // chunk buffers in flight (device and pinned)
+constexpr int MAXBUCKET = 8;       // length buckets of one call (steps-per-thread classes 1, 2, 3, 4, 6, 8, 16)
 
 struct DeviceCtx {
     std::mutex mu;                 // serialises calls on this device
@@ -99,6 +111,8 @@ struct DeviceCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;          // kernel timing
     hipEvent_t ev_scr = nullptr;                      // device entry: last use of the shared scratch (scr, mom) on any stream
     hipEvent_t evk[RING] = {}, evc[RING] = {};        // chunk pipeline: kernel done / copy done
+    hipStream_t bstream[MAXBUCKET - 1] = {};          // length-bucketed dispatch: the shorter buckets' launches run beside the longest
+    hipEvent_t ev_fork = nullptr, ev_join[MAXBUCKET - 1] = {};
     int cu_count = 0;
     Arena dev, pin;
     Arena mom;                     // device entry: the draw-moment tables behind extras.corr
@@ -114,8 +128,9 @@ std::mutex g_init_mu;
 // needs a multi-GPU node.  0 / unset: ids are physical devices.
 int virtual_devices()
 {
-    static const int v = [] { const char* e = getenv("HMCG_VIRTUAL_DEVICES"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, (int)HMCG_MAXDEV) : 0; }();
-    return v;
+    const char* e = diag_env("HMCG_VIRTUAL_DEVICES");          // (diagnostics only: read per call, so a test can switch it)
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? std::min(n, (int)HMCG_MAXDEV) : 0;
 }
 
 // Returns the (created on first use) context of `device`; the caller then locks ctx->mu and calls hipSetDevice(ctx->phys).
@@ -146,6 +161,17 @@ int get_context(int device, DeviceCtx** out)
             HIP_TRY(hipEventCreateWithFlags(&c.evk[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c.evc[i], hipEventDisableTiming));
         }
+        {
+            // the shorter buckets' streams take the lowest priority: where blocks of two buckets compete for a CU, the
+            // longer windows (the call's critical path) are placed first
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            for (int i = 0; i < MAXBUCKET - 1; ++i) {
+                HIP_TRY(hipStreamCreateWithPriority(&c.bstream[i], hipStreamNonBlocking, lo));
+                HIP_TRY(hipEventCreateWithFlags(&c.ev_join[i], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+        }
         HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, c.phys));
         c.pin.pinned = true;
         {
@@ -175,6 +201,13 @@ void destroy_context(DeviceCtx& c)
     (void)hipEventDestroy(c.ev1);
     (void)hipEventDestroy(c.ev_scr);
     for (int i = 0; i < RING; ++i) { (void)hipEventDestroy(c.evk[i]); (void)hipEventDestroy(c.evc[i]); }
+    for (int i = 0; i < MAXBUCKET - 1; ++i) {
+        (void)hipStreamSynchronize(c.bstream[i]);
+        (void)hipStreamDestroy(c.bstream[i]);
+        (void)hipEventDestroy(c.ev_join[i]);
+        c.bstream[i] = nullptr;
+    }
+    (void)hipEventDestroy(c.ev_fork);
     c.dev.release();
     c.pin.release();
     c.mom.release();
@@ -188,7 +221,7 @@ void destroy_context(DeviceCtx& c)
 using namespace hmcg_host;
 using namespace hmcg_hostutil;
 int flavour_of(const Variant& v) { return v.NH > 0 ? H : (v.occ == 2 ? P2 : P1); }
-const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_k3_l16, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
+const VariantGroup* const g_groups[] = { &g_group_k2, &g_group_k3, &g_group_mid, &g_group_k3_l16, &g_group_k4, &g_group_sig, &g_group_smooth, &g_group_sigsmooth };
 
 
 // The variant for (K, longest window, threads per window, path): the fewest steps per thread that cover the
@@ -218,7 +251,7 @@ int validate(const hmcg_config* cfg)
         return HMCG_E_BADARG;
     }
     if (cfg->W < 1 || cfg->K < 2 || cfg->K > HMCG_MAXK || cfg->ldY < 2 || cfg->burnin < 0 || cfg->nrun < 0 ||
-        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0 || cfg->sweep_count < 0 || cfg->n_samples < 0 || cfg->kappa < 0.0) {
+        cfg->H < 0 || cfg->H > HMCG_MAXH || cfg->max_T < 0 || cfg->max_T > cfg->ldY || cfg->sweep_base < 0 || cfg->sweep_count < 0 || cfg->n_samples < 0 || cfg->kappa < 0.0 || cfg->min_T < 0) {
         set_err("bad hmcg_config (W=%d K=%d ldY=%d max_T=%d burnin=%d nrun=%d H=%d)", cfg->W, cfg->K, cfg->ldY,
                 cfg->max_T, cfg->burnin, cfg->nrun, cfg->H);
         return HMCG_E_BADARG;
@@ -233,8 +266,15 @@ int validate(const hmcg_config* cfg)
 }
 
 // What runs: the kernel instantiation for this call's shape, chosen once per call.
+// One length bucket of a call: the windows with t_lo < T <= t_hi run on variant v (its own launch, beside the others).
+struct Bucket {
+    const Variant* v;
+    int t_lo, t_hi;
+};
 struct Plan {
-    const Variant* v = nullptr;
+    const Variant* v = nullptr;    // register-resident kernel (with buckets: the longest bucket's variant)
+    int nb = 0;                    // > 1: length-bucketed dispatch, longest bucket first
+    Bucket b[MAXBUCKET];
     const BigVariant* bv = nullptr;
     int bigL = 0;
     bool stream = false;           // the LDS-resident kernel's HBM-streaming form (window too long for the CU's LDS)
@@ -252,8 +292,49 @@ struct Plan {
     const void* fptr() const { return v ? reinterpret_cast<const void*>(v->fn) : reinterpret_cast<const void*>(bv->fn); }
 };
 
-// Argument checks common to both entries + kernel choice.  W is the number of windows THIS device runs.
-int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count, Plan* plan)
+// Static LDS of a kernel instantiation, asked of the runtime once per function (make_plan and fill_timing sit on the call path).
+size_t static_lds_bytes(const void* fn, size_t fallback)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : cache) if (e.first == fn) return e.second;
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return fallback;      // (not cached: asked again next time)
+    cache.emplace_back(fn, fa.sharedSizeBytes);
+    return fa.sharedSizeBytes;
+}
+
+// The steps-per-thread classes compiled for a path at 256 threads per window, ascending.
+int length_classes(int K, bool sig, bool smooth, int* Ls)
+{
+    int n = 0;
+    for (const VariantGroup* g : g_groups)
+        for (int i = 0; i < g->n; ++i) {
+            const Variant& v = g->v[i];
+            if (v.K != K || v.NT != 256 || v.sig != sig || v.smooth != smooth) continue;
+            bool seen = false;
+            for (int j = 0; j < n; ++j) seen |= Ls[j] == v.L;
+            if (!seen && n < 16) Ls[n++] = v.L;
+        }
+    std::sort(Ls, Ls + n);
+    return n;
+}
+
+int flavour_code(const char* f) { return !strcmp(f, "h") ? H : (!strcmp(f, "p2") ? P2 : P1); }
+
+// The window lengths of a call as the host entries know them (rows idx[0..n) of T; idx == nullptr: rows 0..n-1).
+struct HostLengths {
+    const int32_t* T = nullptr;
+    const int32_t* idx = nullptr;
+    int n = 0;
+    int at(int i) const { return T[idx ? (size_t)idx[i] : (size_t)i]; }
+};
+
+// Argument checks common to both entries + kernel choice.  W is the number of windows THIS device runs; minT the shortest
+// of them when the caller knows it (0: unknown -- one launch sized for the longest window); hl (host entries) the lengths
+// themselves: classes no window falls in are not launched.
+int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count, int minT, const HostLengths* hl, Plan* plan)
 {
     if (ex && ex->struct_size != (int32_t)sizeof(hmcg_extras)) { set_err("hmcg_extras.struct_size mismatch"); return HMCG_E_BADARG; }
     const bool resume = (cfg->flags & HMCG_FLAG_RESUME) != 0;
@@ -289,12 +370,56 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     // HMCG_FLAVOUR=p1|p2|h and HMCG_HELPERS=0|1 override the table (diagnostics, tools/variant_sweep.py).
     const bool small_batch = W <= cu_count;
     int force = -1;
-    if (const char* henv = getenv("HMCG_HELPERS")) force = atoi(henv) != 0 ? H : (small_batch ? P1 : P2);
-    if (const char* fenv = getenv("HMCG_FLAVOUR")) force = !strcmp(fenv, "h") ? H : (!strcmp(fenv, "p2") ? P2 : P1);
+    if (const char* henv = diag_env("HMCG_HELPERS")) force = atoi(henv) != 0 ? H : (small_batch ? P1 : P2);
+    if (const char* fenv = diag_env("HMCG_FLAVOUR")) force = flavour_code(fenv);
     Plan pl;
     pl.use_sig = use_sig; pl.use_smooth = use_smooth;
     // HMCG_FORCE_BIG=1 (diagnostics): the LDS-resident kernel also where a register-resident variant exists
-    if (cfg->K < 5 && !getenv("HMCG_FORCE_BIG")) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
+    if (cfg->K < 5 && !diag_env("HMCG_FORCE_BIG")) pl.v = pick_variant(cfg->K, maxT, cfg->threads_per_window, use_sig, use_smooth, small_batch, force);
+#ifndef HMCG_STAMPS
+    // Length-bucketed dispatch: a batch of ragged windows (the reference's production run: 460 expanding windows of 120..579
+    // months, code/run_hmm.jl:79-109) is cut by the steps-per-thread class each window needs; every class gets its own launch
+    // on its own stream, all of them over the whole grid -- the blocks of the other classes' windows leave at once
+    // (KernelParams::t_lo / t_hi).  A window then runs on the variant its own length selects, whatever else the call holds:
+    // its result equals that of a call with this window alone, bit for bit.  (HMCG_NO_BUCKETS=1, diagnostics: one launch
+    // sized for the longest window, as before round 4.)
+    if (pl.v && pl.v->NT == 256 && cfg->threads_per_window == 0 && minT > 0 && minT < maxT && !diag_env("HMCG_NO_BUCKETS")) {
+        int Ls[16];
+        const int nL = length_classes(cfg->K, use_sig, use_smooth, Ls);
+        int lo = 0, hi = 0;
+        while (lo < nL && 256 * Ls[lo] < minT) ++lo;
+        while (hi < nL && 256 * Ls[hi] < maxT) ++hi;
+        if (hi < nL && lo < hi) {
+            // classes that are launched, longest first: all of them on the device entry (it does not see T); on the host
+            // entries only those a window falls in (the longest one always: it reports, and flags T > max_T)
+            int keep[16], nk = 0;
+            for (int c = hi; c >= lo; --c) {
+                bool any = !hl || c == hi;
+                const int c_lo = c == 0 ? 0 : 256 * Ls[c - 1], c_hi = 256 * Ls[c];
+                for (int i = 0; hl && i < hl->n && !any; ++i) any = hl->at(i) > c_lo && hl->at(i) <= c_hi;
+                if (any) keep[nk++] = c;
+            }
+            nk = std::min(nk, MAXBUCKET);          // (more classes than slots: the last slot's class takes every shorter window too)
+            const char* bf = diag_env("HMCG_BUCKET_FLAVOURS");          // "h,p2,p2": longest bucket first (diagnostics)
+            for (int j = 0; j < nk; ++j) {
+                int f = force;
+                if (bf && *bf) {
+                    char tok[8] = "";
+                    size_t n = strcspn(bf, ",");
+                    memcpy(tok, bf, std::min(n, sizeof tok - 1));
+                    f = flavour_code(tok);
+                    bf += n + (bf[n] == ',' ? 1 : 0);
+                }
+                // bucket j: windows longer than the next kept class holds, up to what this class holds (a skipped class is
+                // empty, so every window still runs on the smallest class that covers it)
+                const int t_hi = j == 0 ? INT32_MAX : 256 * Ls[keep[j]], t_lo = j == nk - 1 ? INT32_MIN : 256 * Ls[keep[j + 1]];
+                pl.b[pl.nb++] = Bucket{pick_variant(cfg->K, 256 * Ls[keep[j]], 0, use_sig, use_smooth, small_batch, f), t_lo, t_hi};
+            }
+            if (pl.nb == 1) pl.nb = 0;             // one class after all: a plain single launch
+            pl.v = pl.b[0].v;
+        }
+    }
+#endif
     if (!pl.v) {                                       // large K, or a window too long for the register-resident variants
         const BigVariant* tab = use_sig ? (use_smooth ? g_big_sigsmooth_variants : g_big_sig_variants) : (use_smooth ? g_big_smooth_variants : g_big_variants);
         const int ntab = use_sig ? (use_smooth ? g_n_big_sigsmooth_variants : g_n_big_sig_variants) : (use_smooth ? g_n_big_smooth_variants : g_n_big_variants);
@@ -303,10 +428,9 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
             pl.bigL = (maxT + pl.bv->NT - 1) / pl.bv->NT;
             pl.dyn = (size_t)pl.bv->NT * pl.bigL * (8 + 8 + 4 + 1) + 16;
             // dynamic + static LDS of the instantiation must fit the CU's 160 KiB
-            hipFuncAttributes fa{};
-            const size_t stat = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pl.bv->fn)) == hipSuccess ? fa.sharedSizeBytes : 48 * 1024;
+            const size_t stat = static_lds_bytes(reinterpret_cast<const void*>(pl.bv->fn), 48 * 1024);
             if (cfg->threads_per_window != 0 && cfg->threads_per_window != pl.bv->NT) pl.bv = nullptr;
-            else if (pl.dyn + stat > 160 * 1024 || getenv("HMCG_FORCE_STREAM")) {
+            else if (pl.dyn + stat > 160 * 1024 || diag_env("HMCG_FORCE_STREAM")) {
                 // too long for the LDS: the same kernel with its per-step arrays in an HBM scratch (HMCG_FORCE_STREAM: tests)
                 pl.bv = nullptr;
                 const BigVariant* stab = use_sig ? (use_smooth ? g_big_sigsmooth_stream_variants : g_big_sig_stream_variants)
@@ -345,6 +469,7 @@ hmcg::KernelParams base_params(const hmcg_config* cfg, int W, const double* dY, 
     p.alpha = cfg->alpha > 0.0 ? cfg->alpha : 1.0;
     p.nu = cfg->nu > 0.0 ? cfg->nu : 1.0;
     p.status = dstatus;
+    p.t_lo = INT32_MIN; p.t_hi = INT32_MAX;
     if (dex) {
         p.pi_smooth_mean = dex->pi_smooth_mean; p.pi_filter_mean = dex->pi_filter_mean; p.pi_smooth_draws = dex->pi_smooth_draws;
         p.sig_range = dex->sig_range; p.save_range = dex->save_range; p.sigma_signal = dex->sigma_signal;
@@ -356,10 +481,29 @@ hmcg::KernelParams base_params(const hmcg_config* cfg, int W, const double* dY, 
     return p;
 }
 
-void launch_kernel(const Plan& pl, const hmcg::KernelParams& p, hipStream_t stream)
+int launch_kernel(DeviceCtx& c, const Plan& pl, const hmcg::KernelParams& p, hipStream_t stream)
 {
+    if (pl.nb > 1) {
+        // fork: every bucket's launch waits for what precedes this call on `stream`; the longest bucket runs on `stream`
+        // itself, the others on the context's bucket streams; join: `stream` waits for all of them
+        HIP_TRY(hipEventRecord(c.ev_fork, stream));
+        for (int b = 0; b < pl.nb; ++b) {
+            hipStream_t bs = b == 0 ? stream : c.bstream[b - 1];
+            if (b > 0) HIP_TRY(hipStreamWaitEvent(bs, c.ev_fork, 0));
+            hmcg::KernelParams q = p;
+            q.t_lo = pl.b[b].t_lo; q.t_hi = pl.b[b].t_hi;
+            const Variant* v = pl.b[b].v;
+            hipLaunchKernelGGL(v->fn, dim3((unsigned)p.W), dim3((unsigned)(v->NT + 64 * v->NH)), 0, bs, q);
+            HIP_TRY(hipGetLastError());
+            if (b > 0) HIP_TRY(hipEventRecord(c.ev_join[b - 1], bs));
+        }
+        for (int b = 1; b < pl.nb; ++b) HIP_TRY(hipStreamWaitEvent(stream, c.ev_join[b - 1], 0));
+        return 0;
+    }
     if (pl.v) hipLaunchKernelGGL(pl.v->fn, dim3((unsigned)p.W), dim3((unsigned)(pl.v->NT + 64 * pl.v->NH)), 0, stream, p);
     else hipLaunchKernelGGL(pl.bv->fn, dim3((unsigned)p.W), dim3((unsigned)pl.bv->NT), pl.dyn, stream, p, pl.bigL);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 void fill_timing(hmcg_timing* t, const Plan& pl, const DeviceCtx& c, double kernel_ms, int launches, double call_ms, int windows)
@@ -374,9 +518,9 @@ void fill_timing(hmcg_timing* t, const Plan& pl, const DeviceCtx& c, double kern
     t->call_ms = call_ms;
     t->windows = windows;
     t->occupancy = pl.v ? pl.v->occ : 0;
-    t->lds_bytes = 0;
-    hipFuncAttributes fa{};
-    if (hipFuncGetAttributes(&fa, pl.fptr()) == hipSuccess) t->lds_bytes = (int32_t)(fa.sharedSizeBytes + pl.dyn);
+    t->buckets = pl.nb > 1 ? pl.nb : 1;
+    t->reserved = 0;
+    t->lds_bytes = (int32_t)(static_lds_bytes(pl.fptr(), 0) + pl.dyn);
 }
 
 #ifdef HMCG_STAMPS
@@ -389,7 +533,7 @@ int print_stamps(const hmcg::KernelParams& p, const Plan& pl, unsigned long long
     HIP_TRY(hipStreamSynchronize(stream));
     // HMCG_STAMPS_AFTER=n: stay silent for the first n launches (tools/stamps.py warms the chip up for >= 2 s first)
     static int launches_seen = 0;
-    static const int print_after = getenv("HMCG_STAMPS_AFTER") ? atoi(getenv("HMCG_STAMPS_AFTER")) : 0;
+    static const int print_after = diag_env("HMCG_STAMPS_AFTER") ? atoi(diag_env("HMCG_STAMPS_AFTER")) : 0;
     if (launches_seen++ < print_after) return 0;
     HIP_TRY(hipMemcpy(h.data(), ddbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     const int nsw = p.sweep_end - p.sweep_begin;
@@ -439,7 +583,7 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
 {
     if (!dY || !dT || !dstatus) { set_err("Y, T and status are required"); return HMCG_E_BADARG; }
     Plan pl;
-    int rc = make_plan(cfg, ex, cfg->W, c.cu_count, &pl);
+    int rc = make_plan(cfg, ex, cfg->W, c.cu_count, cfg->min_T, nullptr, &pl);
     if (rc) return rc;
     if (pl.needs_pif() && !(ex && ex->pif_final)) {
         set_err("pi_smooth_mean / pi_filter_mean for K >= 5 or windows beyond the register-resident kernels need extras.pif_final "
@@ -483,8 +627,8 @@ int launch_device(DeviceCtx& c, const hmcg_config* cfg, const double* dY, const 
     HIP_TRY(hipMemsetAsync(ddbg, 0, ndbg * sizeof(unsigned long long), stream));
     p.dbg = ddbg;
 #endif
-    launch_kernel(pl, p, stream);
-    HIP_TRY(hipGetLastError());
+    rc = launch_kernel(c, pl, p, stream);
+    if (rc) return rc;
     if (ex && ex->corr) {
         // correlations of the rounded draws (calccorr): one pass over the draw arrays while they are in HBM
         const size_t mbytes = sizeof(double) * (size_t)cfg->W * hmcg_host::moments_stride(cfg->K);
@@ -524,18 +668,26 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
 {
     const auto t_call = std::chrono::steady_clock::now();
     // HMCG_TRACE=1 (diagnostics): host-side timeline of the call on stderr -- where the wall time beyond the kernels goes
-    static const bool trace_on = getenv("HMCG_TRACE") != nullptr;
+    static const bool trace_on = diag_env("HMCG_TRACE") != nullptr;
     std::vector<std::pair<const char*, double>> trace;
     auto mark = [&](const char* what) {
         if (trace_on) trace.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
     };
     // HMCG_FAIL_DEVICE=id (diagnostics): the host entry fails on that device id before it touches anything -- lets a test
     // see hmcg_estimate_batch_multi report one worker's error while the others complete
-    if (const char* fe = getenv("HMCG_FAIL_DEVICE")) {
+    if (const char* fe = diag_env("HMCG_FAIL_DEVICE")) {
         if (atoi(fe) == c.device) { set_err("injected failure (HMCG_FAIL_DEVICE=%d)", c.device); return HMCG_E_NOMEM; }
     }
     Plan pl;
-    int rc = make_plan(cfg, h.ex, n, c.cu_count, &pl);
+    int minT = 0;                                                  // the shortest valid window of this device's share
+    if (h.T) {
+        for (int i = 0; i < n; ++i) {
+            const int t = h.T[idx ? (size_t)idx[i] : (size_t)i];
+            if (t >= 2 && (minT == 0 || t < minT)) minT = t;
+        }
+    }
+    const HostLengths hl{h.T, idx, n};
+    int rc = make_plan(cfg, h.ex, n, c.cu_count, minT, h.T ? &hl : nullptr, &pl);
     if (rc) return rc;
     if (!h.Y || !h.T) { set_err("Y and T are required"); return HMCG_E_BADARG; }
     const hmcg_extras* ex = h.ex;
@@ -544,6 +696,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const long long nd_total = (long long)n_samples * cfg->nrun;       // kept draws per window over the whole run
     const size_t NS = 3 * K + K * K + 2 * H;
     const bool resume_in = (cfg->flags & HMCG_FLAG_RESUME) != 0;
+    constexpr int32_t ST_SKIPPED = HMCG_ST_NONFINITE | HMCG_ST_BAD_T | HMCG_ST_BAD_RANGE;
     auto row = [&](int i) -> size_t { return idx ? (size_t)idx[i] : (size_t)i; };
 
     // per-draw output columns of one window, in the order they sit in a chunk buffer
@@ -572,9 +725,10 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         const long long budget = (1LL << 30) / RING / (long long)(8 * ncols * N);
         cap = std::max(1LL, std::min(cap, budget));
     }
-    if (const char* cenv = getenv("HMCG_CHUNK_DRAWS")) { const long long v = atoll(cenv); if (v > 0) cap = std::min(cap, v); }
-    const bool one_chunk_env = getenv("HMCG_NO_CHUNKS") != nullptr;           // diagnostics: one launch, as the device entry
-    std::vector<Chunk> chunks = plan_chunks(sb, se, per, cfg->burnin, cfg->nrun, one_chunk_env ? (1LL << 40) : cap, stream_draws && !one_chunk_env);
+    if (const char* cenv = diag_env("HMCG_CHUNK_DRAWS")) { const long long v = atoll(cenv); if (v > 0) cap = std::min(cap, v); }
+    const bool one_chunk_env = diag_env("HMCG_NO_CHUNKS") != nullptr;           // diagnostics: one launch, as the device entry
+    std::vector<Chunk> chunks = plan_chunks(sb, se, per, cfg->burnin, cfg->nrun, one_chunk_env ? (1LL << 40) : cap, stream_draws && !one_chunk_env,
+                                            diag_env("HMCG_CHUNK_FLOOR_DIV"), diag_env("HMCG_CHUNK_KEEP"));
     long long chunk_max = 0;
     for (const Chunk& ch : chunks) chunk_max = std::max(chunk_max, ch.d1 - ch.d0);
     const bool chunked = chunks.size() > 1;
@@ -627,6 +781,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     // pinned staging beyond the input block: small outputs (status | summary adjacent, as on the device), chunk ring, extras
     const size_t o_pst = LP.add(4 * N);
     const size_t o_psum = h.summary ? LP.add(8 * N * NS) : 0;
+    const size_t o_pst0 = LP.add(4 * N);      // status words as they stand after the first launch: which windows were skipped
     for (int r = 0; r < nring; ++r) o_pchunk[r] = LP.add(chunk_bytes);
     const size_t o_pxs = need_ckpt ? LP.add(N * ld) : 0, o_pacc = need_ckpt ? LP.add(8 * N * (NS + K)) : 0;
     const size_t o_pxf = want_xf ? LP.add(4 * N * ld) : 0;
@@ -652,7 +807,8 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         PP(int32_t, o_pT)[i] = h.T[g];
         PP(uint32_t, o_pwid)[i] = (ex && ex->window_ids) ? ex->window_ids[g] : cfg->window_base + (uint32_t)g;
         if (h.yreal && H) memcpy(PP(double, o_pyr) + (size_t)i * H, h.yreal + g * H, 8 * H);
-        if (resume_in) PP(int32_t, o_pst)[i] = h.status ? h.status[g] : 0;
+        // (a RESUME call carries the caller's status words on; whether a window is skipped is for THIS call's kernel to say)
+        if (resume_in) PP(int32_t, o_pst)[i] = h.status ? (h.status[g] & ~ST_SKIPPED) : 0;
         if (want_xi) memcpy(PP(int32_t, o_pxi) + (size_t)i * ld, ex->x_init + g * ld, 4 * ld);
         if (ex && ex->sig_range) { PP(int32_t, o_psr)[2 * i] = ex->sig_range[2 * g]; PP(int32_t, o_psr)[2 * i + 1] = ex->sig_range[2 * g + 1]; }
         if (ex && ex->save_range) { PP(int32_t, o_psvr)[2 * i] = ex->save_range[2 * g]; PP(int32_t, o_psvr)[2 * i + 1] = ex->save_range[2 * g + 1]; }
@@ -721,10 +877,15 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     mark("inputs enqueued");
     const int nch = (int)chunks.size();
     double kernel_ms = 0.0;
-    std::vector<hipEvent_t> tev;          // per-chunk timing events (created only when timing is requested)
+    // per-chunk timing events, two per chunk: around the sweep kernel(s) alone -- the copy-out of the last chunk rides the
+    // same stream behind its kernel and is not kernel time.  (Created only when timing is requested; released on every path.)
+    struct TimingEvents {
+        std::vector<hipEvent_t> ev;
+        ~TimingEvents() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } tev;
     if (timing) {
-        tev.resize((size_t)nch + 1);
-        for (auto& e : tev) HIP_TRY(hipEventCreate(&e));
+        tev.ev.assign(2 * (size_t)nch, nullptr);
+        for (auto& e : tev.ev) HIP_TRY(hipEventCreate(&e));
     }
     auto scatter = [&](int cidx) {
         const Chunk& ch = chunks[cidx];
@@ -735,8 +896,15 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             const int i0 = (int)((long long)n * pi / np), i1 = (int)((long long)n * (pi + 1) / np);
             for (int i = i0; i < i1; ++i) {
                 const size_t g = row(i);
+                // a skipped window produced nothing -- its block of the (recycled) chunk buffer holds an earlier call's bytes:
+                // the contract (hmcg.h) says its outputs read zero
+                const bool skipped = (PP(int32_t, o_pst0)[i] & ST_SKIPPED) != 0;
                 for (const Col& cc : cols) {
                     if (!cc.host) continue;
+                    if (skipped) {
+                        for (size_t q = 0; q < cc.ncol; ++q) memset(cc.host + (size_t)nd_total * (q + cc.ncol * g) + (size_t)ch.d0, 0, 8 * ndc);
+                        continue;
+                    }
                     const bool per_step = &cc == &cols[5];          // pi_smooth_draws: column = k * ldY + t; the kernel writes t < T[w] only
                     const size_t Tg = per_step ? (size_t)std::max(0, std::min((int)ld, (int)h.T[g])) : 0;
                     for (size_t q = 0; q < cc.ncol; ++q) {
@@ -778,21 +946,25 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             p.pi_end = cols[3].ncol ? cb + ndc * cols[3].off * N : nullptr;
             p.fcast = cols[4].ncol ? cb + ndc * cols[4].off * N : nullptr;
             p.pi_smooth_draws = cols[5].ncol ? cb + ndc * cols[5].off * N : nullptr;
-            // (a skipped window writes nothing into its block: its rows of the caller's arrays are zeroed at the end of the
-            //  call, once the status words are back -- no memset node per chunk on the stream)
+            // (a skipped window writes nothing into its block: the scatter zeroes its rows of the caller's arrays instead of
+            //  copying them -- no memset node per chunk on the stream)
         }
-        if (timing) HIP_TRY(hipEventRecord(tev[(size_t)cidx], s));
-        launch_kernel(pl, p, s);
-        HIP_TRY(hipGetLastError());
+        if (timing) HIP_TRY(hipEventRecord(tev.ev[2 * (size_t)cidx], s));
+        rc = launch_kernel(c, pl, p, s);
+        if (rc) return rc;
+        if (timing) HIP_TRY(hipEventRecord(tev.ev[2 * (size_t)cidx + 1], s));
         if (stream_draws) {
             // the last chunk's copy-out hides behind nothing: it goes on the compute stream itself, right behind its kernel,
             // instead of paying a cross-stream event hand-off at the tail of the call
-            const bool tail_copy = cidx == nch - 1 && !want_corr && getenv("HMCG_NO_TAIL_COPY") == nullptr;
+            const bool tail_copy = cidx == nch - 1 && !want_corr && diag_env("HMCG_NO_TAIL_COPY") == nullptr;
             hipStream_t cs = tail_copy ? s : c.copy;
             if (!tail_copy) {
                 HIP_TRY(hipEventRecord(c.evk[slot], s));
                 HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
             }
+            // skips are decided in the first launch's prologue: its status words travel with the first chunk, so that the
+            // scatter knows which windows' blocks hold nothing
+            if (cidx == 0 && copy_out) HIP_TRY(hipMemcpyAsync(P + o_pst0, D + o_dst, 4 * N, hipMemcpyDeviceToHost, cs));
             if (ndc > 0 && copy_out)
                 HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, cs));
             HIP_TRY(hipEventRecord(c.evc[slot], cs));
@@ -805,7 +977,6 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         }
     }
     mark("kernels enqueued");
-    if (timing) HIP_TRY(hipEventRecord(tev[(size_t)nch], s));
     if (want_corr) HIP_TRY(hmcg_host::launch_corr_finalize(DP(double, o_dmom), DP(double, o_dcorr), n, cfg->K, s));
 
     // ---- small outputs and one-off extras: D2H on the compute stream (after the last kernel) ----
@@ -832,19 +1003,10 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     mark("chunks scattered");
     HIP_TRY(hipStreamSynchronize(s));
     mark("stream idle");
-    constexpr int32_t ST_SKIPPED = HMCG_ST_NONFINITE | HMCG_ST_BAD_T | HMCG_ST_BAD_RANGE;
     for (int i = 0; i < n; ++i) {
         const size_t g = row(i);
-        if (PP(int32_t, o_pst)[i] & ST_SKIPPED) {
-            // a skipped window produced nothing: what the scatter copied for it is whatever the chunk buffers held; the
-            // contract (hmcg.h) says its outputs read zero
-            const size_t d0 = (size_t)chunks.front().d0, dn = (size_t)(chunks.back().d1 - chunks.front().d0);
-            if (copy_out && dn > 0)
-                for (const Col& cc : cols)
-                    if (cc.host)
-                        for (size_t q = 0; q < cc.ncol; ++q) memset(cc.host + (size_t)nd_total * (q + cc.ncol * g) + d0, 0, 8 * dn);
-            if (want_corr) memset(PP(double, o_pcorr) + (size_t)i * NCC * NCC, 0, 8 * NCC * NCC);
-        }
+        // (a skipped window's per-draw rows were zeroed by the scatter, chunk by chunk; its correlation matrix here)
+        if (want_corr && (PP(int32_t, o_pst)[i] & ST_SKIPPED)) memset(PP(double, o_pcorr) + (size_t)i * NCC * NCC, 0, 8 * NCC * NCC);
         if (h.status) h.status[g] = PP(int32_t, o_pst)[i];
         if (h.summary) memcpy(h.summary + g * NS, PP(double, o_psum) + (size_t)i * NS, 8 * NS);
         if (want_xf) memcpy(ex->x_final + g * ld, PP(int32_t, o_pxf) + (size_t)i * ld, 4 * ld);
@@ -868,10 +1030,9 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (timing) {
         for (int cidx = 0; cidx < nch; ++cidx) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, tev[(size_t)cidx], tev[(size_t)cidx + 1]));
-            kernel_ms += ms;       // includes the chunk's memset and any wait for a ring slot
+            HIP_TRY(hipEventElapsedTime(&ms, tev.ev[2 * (size_t)cidx], tev.ev[2 * (size_t)cidx + 1]));
+            kernel_ms += ms;       // the chunk's sweep kernel(s); a wait for a ring slot falls before the first event
         }
-        for (auto& e : tev) (void)hipEventDestroy(e);
         const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
         fill_timing(timing, pl, c, kernel_ms, nch, call_ms, n);
     }

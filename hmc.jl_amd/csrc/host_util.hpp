@@ -97,20 +97,21 @@ inline long long sweep_after_kept(long long d, int per, int burnin, int nrun)
 struct Chunk { int s0, s1; long long d0, d1; };   // sweeps [s0, s1) produce the kept draws [d0, d1)
 
 // Chunks of the sweep range [sb, se): draw counts halve from chunk to chunk down to ~1/32 of the run (the last chunk's
-// copy-out is the only one not hidden behind sampling; HMCG_CHUNK_FLOOR_DIV overrides the 32), never more than `cap`
-// draws in a chunk.
-inline std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int nrun, long long cap, bool stream_draws)
+// copy-out is the only one not hidden behind sampling), never more than `cap` draws in a chunk.  fdiv_env / keep_env:
+// diagnostic overrides of the 32 and of the share a chunk takes ("num/den"), nullptr in production (hmcg.hip, diag_env).
+inline std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int nrun, long long cap, bool stream_draws,
+                                      const char* fdiv_env = nullptr, const char* keep_env = nullptr)
 {
     std::vector<Chunk> out;
     const long long dB = kept_before(sb, per, burnin, nrun), dE = kept_before(se, per, burnin, nrun);
     const long long nd = dE - dB;
     if (!stream_draws || nd <= 0 || se <= sb) { out.push_back({sb, se, dB, dE}); return out; }
     long long fdiv = 32;       // (measured at the headline shape: 1/8 5.34 ms, 1/16 5.30, 1/32 5.23 per call)
-    if (const char* e = getenv("HMCG_CHUNK_FLOOR_DIV")) { const long long v = atoll(e); if (v >= 2 && v <= 1024) fdiv = v; }
+    if (const char* e = fdiv_env) { const long long v = atoll(e); if (v >= 2 && v <= 1024) fdiv = v; }
     const long long floor_sz = std::max(16LL, nd / fdiv);
-    // share of the remaining draws a chunk takes (HMCG_CHUNK_KEEP=num/den, diagnostics; default 1/2)
+    // share of the remaining draws a chunk takes (default 1/2)
     long long keep_num = 1, keep_den = 2;
-    if (const char* e = getenv("HMCG_CHUNK_KEEP")) {
+    if (const char* e = keep_env) {
         long long a = 0, b = 0;
         if (sscanf(e, "%lld/%lld", &a, &b) == 2 && a >= 1 && b > a && b <= 64) { keep_num = a; keep_den = b; }
     }

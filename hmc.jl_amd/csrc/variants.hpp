@@ -24,7 +24,7 @@ struct VariantGroup {
     int n;
 };
 // register-resident kernels (gibbs_device.hpp): base path by K, signal path, smoothed-probability path
-extern const VariantGroup g_group_k2, g_group_k3, g_group_k3_l16, g_group_k4, g_group_sig, g_group_smooth, g_group_sigsmooth;
+extern const VariantGroup g_group_k2, g_group_k3, g_group_mid, g_group_k3_l16, g_group_k4, g_group_sig, g_group_smooth, g_group_sigsmooth;
 
 using BigKernelFn = void (*)(const hmcg::KernelParams, const int);
 struct BigVariant {

@@ -29,6 +29,8 @@ class DevicePanel:
         H = len(self.horizons)
         self.NS = 3 * K + K * K + 2 * H
         self.max_T = int(np.max(T))
+        Tv = np.asarray(T)[np.asarray(T) >= 2]
+        self.min_T = int(Tv.min()) if Tv.size else 0      # hint for the length-bucketed dispatch (hmcg_config.min_T)
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.Y = torch.from_numpy(Y).to(self.dev)
         self.T = torch.from_numpy(np.ascontiguousarray(T, dtype=np.int32)).to(self.dev)
@@ -55,11 +57,13 @@ class DevicePanel:
     def _ptr(t):
         return 0 if t is None else t.data_ptr()
 
-    def run(self, burnin, seed=1234, window_base=0, threads_per_window=0, timed=True, stream=None):
+    def run(self, burnin, seed=1234, window_base=0, threads_per_window=0, timed=True, stream=None, bucketed=True):
         """One batched estimate call (burnin + nrun sweeps per window).  With timed=True
-        the call waits for completion and returns the HIP-event kernel time in ms."""
+        the call waits for completion and returns the HIP-event kernel time in ms.
+        bucketed=False withholds the min_T hint: one launch sized for the longest window."""
         cfg = _lib.make_config(self.W, self.K, self.ldY, self.max_T, burnin, self.nrun, self.horizons, seed,
-                               window_base, self.device_index, 0, threads_per_window)
+                               window_base, self.device_index, 0, threads_per_window,
+                               min_T=self.min_T if bucketed else 0)
         ex = None
         if self.window_ids is not None or self.corr is not None:
             ex = _lib.Extras()

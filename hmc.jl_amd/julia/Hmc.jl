@@ -54,6 +54,8 @@ struct hmcg_config
     kappa::Float64
     n_samples::Int32
     blend_mask::Int32
+    min_T::Int32                      # device entry: hint for the length-bucketed dispatch (host entries ignore it)
+    reserved3::Int32
 end
 
 struct hmcg_extras
@@ -81,7 +83,7 @@ end
 const HMCG_MAXTAIL = 256
 const HMCG_MAXDEV = 16
 
-struct hmcg_timing                    # include/hmcg.h (ABI 106)
+struct hmcg_timing                    # include/hmcg.h (ABI 107)
     kernel_ms::Float64
     launches::Int32
     threads_per_window::Int32
@@ -92,6 +94,8 @@ struct hmcg_timing                    # include/hmcg.h (ABI 106)
     call_ms::Float64
     windows::Int32
     occupancy::Int32
+    buckets::Int32
+    reserved::Int32
 end
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))
@@ -189,7 +193,7 @@ function estimatewindows(opts::Vector{estopt}; device::Integer=0, devices=nothin
     hz = ntuple(i -> i <= H ? Int32(o.horizons[i]) : Int32(0), HMCG_MAXH)
     cfg = Ref(hmcg_config(Int32(sizeof(hmcg_config)), W, K, ldY, Int32(maximum(Ts)), o.burnin, nrun, H, hz,
                           UInt64(o.seed), UInt32(0), Int32(device), Int32(0), Int32(0), Int32(0), Int32(0), 0.0, 0.0,
-                          0.0, Int32(0), Int32(0)))
+                          0.0, Int32(0), Int32(0), Int32(0), Int32(0)))
     NS = 3K + K * K + 2H
     μ = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
     σ = keepdraws ? Array{Float64}(undef, nrun, K, W) : Float64[]
@@ -254,7 +258,7 @@ function _signal_call(opt::estopt, burnin, nrun, n_samples, σsignal, κ, α, ν
     hz = ntuple(i -> i <= H ? Int32(devh[i]) : Int32(0), HMCG_MAXH)
     cfg = Ref(hmcg_config(Int32(sizeof(hmcg_config)), 1, K, length(Y), length(Y), burnin, nrun, H, hz, UInt64(opt.seed),
                           UInt32(0), Int32(device), Int32(0), Int32(0), Int32(0), Int32(0), Float64(α), Float64(ν), Float64(κ),
-                          Int32(n_samples), Int32(blend)))
+                          Int32(n_samples), Int32(blend), Int32(0), Int32(0)))
     sig = Int32[first(opt.signalRange) - 1, last(opt.signalRange)]                 # 0-based [begin, end)
     nsave = length(opt.signalSave)
     sv = nsave > 0 ? Int32[first(opt.signalSave) - 1, last(opt.signalSave)] : Int32[0, 0]

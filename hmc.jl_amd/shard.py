@@ -35,20 +35,22 @@ def contiguous_blocks(W, world_size):
     return [list(range(edges[r], edges[r + 1])) for r in range(world_size)]
 
 
-def gather_blocks(local_block, local_ids, W_total, group=None, dst=0):
+def gather_blocks(local_block, local_ids, W_total, group=None, dst=0, force_collective=False):
     """Gather per-window rows to rank `dst`, placed at their global ids.
 
     local_block: torch tensor (n_local, C) on this rank (cuda -> RCCL, cpu -> gloo).
     local_ids:   the global window ids of its rows.
     Returns a (W_total, C) tensor on rank dst, None elsewhere.  Blocks are padded to a
     common row count so one all_gather moves everything (ranks differ by at most one
-    window under partition_windows)."""
+    window under partition_windows).
+    force_collective: take the collective branch (padding, ids column, dist.gather) at world size 1 too -- lets a one-GPU
+    box run RCCL's load, communicator creation and this function's whole exchange path (tests/test_gpu_rccl.py)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     ids = torch.as_tensor(list(local_ids), dtype=torch.int64, device=local_block.device)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         out = torch.zeros((W_total, local_block.shape[1]), dtype=local_block.dtype, device=local_block.device)
         out[ids] = local_block
         return out

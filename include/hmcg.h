@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define HMCG_VERSION 106
+#define HMCG_VERSION 107
 #define HMCG_MAXH 8
 #define HMCG_MAXTAIL 256        /* most signal steps past the end date (sigLen, src/Hmc.jl:888) */
 #define HMCG_MAXK 8
@@ -108,6 +108,13 @@ typedef struct hmcg_config {
     int32_t blend_mask;      /* signal path: bit k set = horizon k equals sigLen and is reported through forecastsignal
                                 (src/Hmc.jl:670-681, :908-909): sum_i pi_last[i] (a Yfake[T-1] + (1-a) mu[i]), a = tau/(1+tau),
                                 tau = 1/sigma_signal[w]; horizons[k] is then ignored.  0 otherwise */
+    int32_t min_T;           /* device entry, optional hint: min over w of T[w] (0: unknown).  With it a ragged batch -- the
+                                reference's production run is 460 expanding windows of 120..579 months, code/run_hmm.jl:79-109 --
+                                is dispatched by length: every window runs on the steps-per-thread variant its OWN length
+                                selects (one launch per length class, side by side), and its result is that of a call with
+                                this window alone.  Without it one launch is sized for max_T.  The host entries read T
+                                themselves and ignore the field */
+    int32_t reserved3;
 } hmcg_config;
 
 /* Optional debug / teacher-forcing / checkpoint buffers (all may be NULL).  Pointer
@@ -184,6 +191,9 @@ typedef struct hmcg_timing {
     int32_t windows;         /* windows this device ran */
     int32_t occupancy;       /* register-resident kernels: 1 = the whole register file per window, 2 = capped so that two windows
                                 share a CU (the OCC template argument of the kernel that ran); 0 for the LDS-resident kernel */
+    int32_t buckets;         /* length classes the call was dispatched in (1: one launch for every window); threads_per_window,
+                                steps_per_thread, helper_waves, occupancy and lds_bytes then describe the LONGEST class */
+    int32_t reserved;
 } hmcg_timing;
 
 int hmcg_version(void);

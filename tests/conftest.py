@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# arms the library's diagnostic switches (HMCG_FORCE_STREAM, HMCG_VIRTUAL_DEVICES, HMCG_NO_BUCKETS, ...): read once, when the
+# library is first used, so it is set before anything loads it; child processes the tests start inherit it
+os.environ.setdefault("HMCG_DIAG", "1")
 
 
 def pytest_configure(config):

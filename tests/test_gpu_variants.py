@@ -21,7 +21,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 def variant_rows():
     """(K, L, path) triples parsed from the HMCG_V3 rows of the variant tables (three flavours each)."""
     rows = []
-    for fn in ("variants_k2.hip", "variants_k3.hip", "variants_k3_l16.hip", "variants_k4.hip", "variants_sig.hip", "variants_smooth.hip"):
+    for fn in ("variants_k2.hip", "variants_k3.hip", "variants_mid.hip", "variants_k3_l16.hip", "variants_k4.hip", "variants_sig.hip", "variants_smooth.hip"):
         text = open(os.path.join(CSRC, fn)).read()
         for m in re.finditer(r"HMCG_V3\((\d+),\s*(\d+),\s*(true|false),\s*(true|false)", text):
             K, L, sig, sm = int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true"

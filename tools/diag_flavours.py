@@ -1,5 +1,6 @@
 """Diagnostic: the flavour-identity cases of tests/test_gpu_parity.py one call at a time, announcing each before it runs."""
 import os, sys
+os.environ.setdefault("HMCG_DIAG", "1")      # arms the library's diagnostic switches (read once at first use)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hmc_jl_amd

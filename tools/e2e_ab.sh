@@ -1,4 +1,5 @@
 #!/bin/bash
+export HMCG_DIAG=1   # arms the library's diagnostic switches (read once at first use)
 # End-to-end (host entry) call time of the headline shape under different pipeline settings, same box, interleaved:
 #   gpurun -- 'bash tools/e2e_ab.sh "HMCG_SCATTER_THREADS=0" "HMCG_SCATTER_THREADS=3" "HMCG_CHUNK_FLOOR_DIV=32"'
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HMCG_DIAG=1   # arms the library's diagnostic switches (read once at first use)
 # host-entry call time (plain-C caller, median of 20) under chunk-schedule settings: gpurun -- 'bash tools/e2e_sweep.sh'
 for cfg in "" "HMCG_NO_TAIL_COPY=1" "HMCG_CHUNK_KEEP=3/4" "HMCG_CHUNK_KEEP=3/4 HMCG_CHUNK_FLOOR_DIV=64" "HMCG_CHUNK_KEEP=2/3 HMCG_CHUNK_FLOOR_DIV=64" "HMCG_CHUNK_KEEP=5/8" "HMCG_CHUNK_FLOOR_DIV=64" "HMCG_CHUNK_KEEP=7/8 HMCG_CHUNK_FLOOR_DIV=64"; do
   for rep in 1 2; do

@@ -1,6 +1,7 @@
 """Host-side timeline of hmcg_estimate_batch at the headline shape (HMCG_TRACE=1: the library prints where the wall time of
 a call goes), through the plain-C driver so that no Python sits in the process.  usage: python tools/trace_host_entry.py"""
 import os, struct, subprocess, sys, tempfile
+os.environ.setdefault("HMCG_DIAG", "1")      # arms the library's diagnostic switches (read once at first use)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from hmc_jl_amd import synth

@@ -4,6 +4,7 @@ file), p2 (plain, two blocks per CU), h (four helper waves) -- at one window per
 Usage: python tools/variant_sweep.py [draws]"""
 import ctypes as C
 import os
+os.environ.setdefault("HMCG_DIAG", "1")      # arms the library's diagnostic switches (read once at first use)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
