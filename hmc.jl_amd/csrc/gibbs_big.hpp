@@ -23,7 +23,7 @@
 namespace hmcg {
 
 template <int K>
-struct ThetaBufBig {
+struct alignas(16) ThetaBufBig {       // (16-byte rows: the assembly product loop reads A by ds_read_b128)
     double mu[K], sig2[K], isd[K], coef[K], rho[K];
     double A[K][K];               // row-major, unsorted labels
     double At[K][K];              // At[s][r] = A[r][s]: column s contiguous
@@ -121,6 +121,13 @@ __device__ __forceinline__ void count_le_sorted_batch(const double (&c)[K][K], c
     for (int s = 0; s < K; ++s) idx[s] = (b1[s] ? 4 : 0) + (b2[s] ? 2 : 0) + ((m3[s] <= thr[s]) ? 1 : 0);
 }
 
+// A value that is the same in every lane, moved to scalar registers: as an operand of a VALU instruction it then costs no
+// vector register and no LDS read (one scalar operand per instruction: the constant-bus limit of gfx9).
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // Where the per-step arrays (observations, uniforms, state maps, states) live: LDS, or -- STREAM -- the window's slab of an
 // HBM scratch (global address space, so that the accesses are global_*, never flat_*): the same code either way.
 template <bool GLOBAL, class T> struct StepPtr { using type = T*; };
@@ -156,8 +163,15 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     const DPtr uxs = ylds + cap;                                    // [cap] uniforms of the running sweep
     const UPtr maps = (UPtr)(ylds + 2 * (size_t)cap);               // [cap] state maps g_t
     const BPtr xs = (BPtr)(maps + cap);                             // [cap + 8] states
-    // HBM scratch of this thread's per-step pdfs, [L][K] with the thread index fastest (p.fscr is [W][L][K][NT])
-    double* const fscr = p.fscr + (size_t)blockIdx.x * L * K * NT + threadIdx.x;
+    // HBM scratch of the window's per-step pdfs, p.fscr is [W][L][KP][NT][2]: the K values of a step as KP = ceil(K/2) PAIRS,
+    // the thread index next (a wave's access to a pair is one 1024-byte dwordx4 instruction: half as many vector-memory
+    // instructions as a value at a time -- each costs the lone wave ~50 ticks of issue)
+    constexpr int KP = big_scratch_pairs(K);
+    double* const fscr_w = p.fscr + (size_t)blockIdx.x * L * (2 * KP) * NT;
+    auto fslot = [&](int l, int s, int thread) __attribute__((always_inline)) -> size_t {
+        return (((size_t)l * KP + (size_t)(s >> 1)) * NT + (size_t)thread) * 2 + (size_t)(s & 1);
+    };
+    double* const fscr = fscr_w;          // (indexed through fslot(l, s, threadIdx.x))
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -388,12 +402,12 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 if (tail > 0) {
 #pragma unroll
                     for (int r = 0; r < K; ++r) bsm[r] = 1.0;
-                    const double* fw = p.fscr + (size_t)blockIdx.x * L * K * NT;
+                    const double* fw = fscr_w;
                     for (int j = tail - 1; j >= 0; --j) {
                         const int t = T - tail + j, own = t / L, ll = t - own * L;
                         double g[K], nb[K];
 #pragma unroll
-                        for (int c = 0; c < K; ++c) g[c] = fw[((size_t)ll * K + c) * NT + own] * bsm[c];
+                        for (int c = 0; c < K; ++c) g[c] = fw[fslot(ll, c, own)] * bsm[c];
 #pragma unroll
                         for (int r = 0; r < K; ++r) {
                             double acc = 0.0;
@@ -836,29 +850,187 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         STAMP(2);
         // ---- forward filter: local product of this thread's L matrices A diag(f_t) ----
         double Q[KK];
-#pragma unroll
-        for (int r = 0; r < K; ++r)
-#pragma unroll
-            for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
         double N[KK];
         const bool kept_sweep = SIG ? kept_index(p, sweep) >= 0 : sweep >= p.burnin_s;     // (without the signal path a launch is one sample)
         const bool do_smooth = SM && kept_sweep && (p.pi_smooth_mean != nullptr || p.pi_filter_mean != nullptr || p.pi_smooth_draws != nullptr);
         const int dk = SIG ? kept_index(p, sweep) : sweep - p.burnin_s;      // kept-draw index (meaningful when kept_sweep)
         (void)dk;
-        {
+#ifdef HMCG_BIG_NSC
+        constexpr int NSC = K == 8 ? HMCG_BIG_NSC : 0;     // the first NSC columns of A live in scalar registers for the whole phase
+#else
+        constexpr int NSC = 0;
+#endif
+        double a_sc[NSC > 0 ? NSC : 1][K];
+#pragma unroll
+        for (int s = 0; s < NSC; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) a_sc[s][k] = uniform_f64(Atp[s * K + k]);
+#ifndef HMCG_BIG_NO_ASM                            // (-DHMCG_BIG_NO_ASM: the C++ loop everywhere, for A/B timing)
+        constexpr bool ASM_PRODUCT = K == 8 && !SM;
+#else
+        constexpr bool ASM_PRODUCT = false;
+#endif
+        if constexpr (ASM_PRODUCT) {
+            // K = 8: the pdf pass by itself (every step's K values into the scratch -- the replay reads them there anyway),
+            // then the chunk product as one hand-scheduled assembly loop that reads them back (tools/gen_product_asm.py:
+            // same operations in the same order as the C++ loop below, bit-identical results; 580 VALU instructions per
+            // step instead of ~930, 32 independent chains in flight instead of ~4)
+            // The pdf pass, two steps at a time and STAGE BY STAGE (the same operations per value as pdfs() / exp_tab, so the
+            // same bits): every stage is 2 K independent instructions, and the 2 K table reads of a pair of steps are in
+            // flight together -- left to itself the scheduler runs the K exponentials of a step nearly one after the other,
+            // each waiting for its own table read (7.3 ticks per instruction; staged: measured below).
+            {
+                double mu_s[K], isd_s[K], coef_s[K];         // the emission parameters as scalar operands
+#pragma unroll
+                for (int s = 0; s < K; ++s) { mu_s[s] = uniform_f64(th.mu[s]); isd_s[s] = uniform_f64(th.isd[s]); coef_s[s] = uniform_f64(th.coef[s]); }
+                constexpr int G = 2;
+                // one sched_barrier per operation: the 2 K instances of an operation are issued back to back (independent of
+                // each other), the dependent operation follows as the next group -- written as plain loops the scheduler
+                // keeps each value's chain together and interleaves only two of them (measured: 6.8 ticks per instruction)
+#define HMCG_EACH for (int g = 0; g < G; ++g) _Pragma("unroll") for (int s = 0; s < K; ++s)
+#ifdef HMCG_PDF_NOSB
+#define HMCG_SB
+#else
+#define HMCG_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+                for (int l0 = 0; l0 < L; l0 += G) {
+                    double x[G][K], nn[G][K], tj[G][K], fv[G][K], r[G][K], pp[G][K], yv[G];
+                    int ni[G][K];
+                    unsigned hm[G];
+                    double kf[G];
+                    bool live[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int l = l0 + g < L ? l0 + g : L - 1;       // (an odd L: the last pair computes step L-1 twice)
+                        live[g] = l0 + g < L;
+                        yv[g] = ylds[t0 + l];
+                        kf[g] = (SIG && t0 + l >= sb && t0 + l < se) ? kfac : 1.0;
+                        hm[g] = 0;
+                    }
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH x[g][s] = yv[g] - mu_s[s];
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH x[g][s] = x[g][s] * (isd_s[s] * kf[g]);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH x[g][s] = -(x[g][s] * x[g][s]);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH x[g][s] = fmax(x[g][s], -746.0);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH nn[g][s] = x[g][s] * (EXPTAB_N == 64 ? 92.332482616893657 : 369.3299304675746);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH nn[g][s] = rint(nn[g][s]);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH ni[g][s] = (int)nn[g][s];
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH tj[g][s] = sh.exptab[ni[g][s] & (EXPTAB_N - 1)];
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH r[g][s] = fma(-nn[g][s], EXPTAB_N == 64 ? 1.0830424693267560e-02 : 2.70760617331689e-03, x[g][s]);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH r[g][s] = fma(-nn[g][s], EXPTAB_N == 64 ? 2.9815858269852933e-12 : 7.453964567463233e-13, r[g][s]);
+                    HMCG_SB;
+                    if constexpr (EXPTAB_N == 64) {
+#pragma unroll
+                        HMCG_EACH pp[g][s] = fma(r[g][s], 1.0 / 120.0, 1.0 / 24.0);
+                        HMCG_SB;
+#pragma unroll
+                        HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 1.0 / 6.0);
+                    } else {
+#pragma unroll
+                        HMCG_EACH pp[g][s] = fma(r[g][s], 1.0 / 24.0, 1.0 / 6.0);
+                    }
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 0.5);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 1.0);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 1.0);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH fv[g][s] = tj[g][s] * pp[g][s];
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH fv[g][s] = ldexp(fv[g][s], ni[g][s] >> (EXPTAB_N == 64 ? 6 : 8));
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH fv[g][s] = fv[g][s] * (coef_s[s] * kf[g]);
+                    HMCG_SB;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) hm[g] = max(hm[g], (unsigned)__double2hiint(fv[g][s]));
+                    }
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH fv[g][s] = ldexp(fv[g][s], 1022 - (int)(hm[g] >> 20));
+                    HMCG_SB;
+#undef HMCG_EACH
+#undef HMCG_SB
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hm[0] < 0x01A56E1Fu || hm[1] < 0x01A56E1Fu) != 0ull, 0)) {   // rare, wave-uniform
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            if (hm[g] < 0x01A56E1Fu) {
+                                if (live[g] && t0 + l0 + g < T) st |= HMCG_ST_EMIS_UNDERFLOW;
+#pragma unroll
+                                for (int s = 0; s < K; ++s) fv[g][s] = 1.0;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (live[g]) {
+#pragma unroll
+                            for (int s = 0; s < K; ++s) fscr[fslot(l0 + g, s, threadIdx.x)] = fv[g][s];
+                        }
+                    }
+                }
+            }
+            STAMP(3);
+            const double* asm_fb = fscr_w;
+            const uint32_t asm_voff = (uint32_t)threadIdx.x * 16u;
+            const uint32_t asm_lds = (uint32_t)(uintptr_t)(lds_cdouble*)&th.A[0][0];
+            int asm_l, asm_t, asm_u;
+#if defined(HMCG_BIG_ASM_TESTINC)                 // (timing experiments of tools/gen_product_asm.py --test-*: wrong results)
+#include HMCG_BIG_ASM_TESTINC
+#else
+#include "product_asm_k8.inc"
+#endif
+            (void)asm_l; (void)asm_t; (void)asm_u;
+            rescale_pow2<KK>(Q);
+        } else {
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int s = 0; s < K; ++s) Q[r * K + s] = (r == s) ? 1.0 : 0.0;
             // Q <- Q * (A diag(f_t)), in place, four rows at a time: row r of the product needs row r of Q only, so once a
             // block of rows has all its columns it replaces the block it came from -- one matrix and half a matrix live
             // (192 registers) instead of two (256, i.e. ~190 VGPR<->AGPR copies per step).  One column of A at a time from
             // LDS (wave-uniform address: a broadcast read), the block's rows against it; every column is read once per block
             // (twice per step for K = 8: 64 broadcast reads instead of 32, far from loading the LDS pipe -- a two-rows form
             // that read A four times per step had been LDS-bound).
+#ifdef HMCG_BIG_RB
+            constexpr int RB = HMCG_BIG_RB;
+#else
             constexpr int RB = 4;
+#endif
             for (int l = 0; l < L; ++l) {
                 asm volatile("" ::: "memory");       // keep the A columns as per-step LDS reads (hoisting all 64 would spill)
                 if constexpr (SM) {
                     if (t0 + l >= T) {               // padded steps stay out of the products (identity): the suffix scan
 #pragma unroll                                       //  of the smoothing pass must not see them
-                        for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = 1.0;
+                        for (int s = 0; s < K; ++s) fscr[fslot(l, s, threadIdx.x)] = 1.0;
                         continue;
                     }
                 }
@@ -867,7 +1039,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 // the replay needs the same K values again: they travel through a lane-contiguous HBM scratch (K coalesced
                 // 512-byte stores per wave and step) instead of being recomputed (K exponentials per step)
 #pragma unroll
-                for (int s = 0; s < K; ++s) fscr[((size_t)l * K + s) * NT] = fv[s];
+                for (int s = 0; s < K; ++s) fscr[fslot(l, s, threadIdx.x)] = fv[s];
 #pragma unroll
                 for (int r0 = 0; r0 < K; r0 += RB) {
                     double tb[RB][K];
@@ -875,7 +1047,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     for (int s = 0; s < K; ++s) {
                         double a[K];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) a[k] = Atp[s * K + k];
+                        for (int k = 0; k < K; ++k) a[k] = s < NSC ? a_sc[s < NSC ? s : 0][k] : Atp[s * K + k];
 #pragma unroll
                         for (int rr = 0; rr < RB; ++rr) {
                             if (r0 + rr < K) {
@@ -966,9 +1138,13 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             const bool want_pif = (last_sweep || do_smooth) && p.pif_final != nullptr;
             double fnext[K];                     // pdfs of the step ahead, on their way from the scratch
 #pragma unroll
-            for (int s = 0; s < K; ++s) fnext[s] = fscr[(size_t)s * NT];
-            constexpr int NRES = 2;              // the first columns of A stay in registers: the step's first chains need not wait for LDS
-            double a_first[NRES][K];
+            for (int s = 0; s < K; ++s) fnext[s] = fscr[fslot(0, s, threadIdx.x)];
+#ifdef HMCG_BIG_NSC_REPLAY
+            constexpr int NRES = NSC > 0 ? 0 : 2, NSR = NSC;      // the scalar columns serve the replay as well
+#else
+            constexpr int NRES = 2, NSR = 0;     // the first columns of A stay in registers: the step's first chains need not wait for LDS
+#endif
+            double a_first[NRES > 0 ? NRES : 1][K];
 #pragma unroll
             for (int s = 0; s < NRES; ++s)
 #pragma unroll
@@ -982,7 +1158,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 for (int s = 0; s < K; ++s) fv[s] = fnext[s];
                 if (l + 1 < L) {
 #pragma unroll
-                    for (int s = 0; s < K; ++s) fnext[s] = fscr[((size_t)(l + 1) * K + s) * NT];
+                    for (int s = 0; s < K; ++s) fnext[s] = fscr[fslot(l + 1, s, threadIdx.x)];
                 }
                 double nv[K], total = 0.0;
                 uint32_t mok = 0;
@@ -994,7 +1170,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     for (int s = 0; s < K; ++s) {
                         double a[K];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) a[k] = s < NRES ? a_first[s < NRES ? s : 0][k] : Atp[s * K + k];
+                        for (int k = 0; k < K; ++k) a[k] = s < NSR ? a_sc[s < NSR ? s : 0][k] : (s < NRES ? a_first[s < NRES ? s : 0][k] : Atp[s * K + k]);
                         double acc = av[0] * a[0];
                         cum[s][0] = acc;
 #pragma unroll
@@ -1128,7 +1304,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                         }
                         double fv[K], fb[K], nb[K];
 #pragma unroll
-                        for (int s = 0; s < K; ++s) fv[s] = fscr[((size_t)l * K + s) * NT];    // this step's pdfs, from the product phase
+                        for (int s = 0; s < K; ++s) fv[s] = fscr[fslot(l, s, threadIdx.x)];    // this step's pdfs, from the product phase
 #pragma unroll
                         for (int s = 0; s < K; ++s) fb[s] = fv[s] * b[s];
 #pragma unroll

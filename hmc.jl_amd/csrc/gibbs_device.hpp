@@ -89,7 +89,8 @@ struct KernelParams {
     // of upstream's runaggregate over a signal run, src/Hmc.jl:1025-1057); the raw running sums while a sample is incomplete
     double* sample_summary;
     // LDS-resident kernel (gibbs_big.hpp) only: scratch that hands each step's K pdfs from the product phase to the replay,
-    // [W][L][K][NT] (thread index fastest: coalesced); library-owned
+    // [W][L][KP][NT][2] with KP = big_scratch_pairs(K) (a pair of values per thread, thread index next: coalesced 16-byte
+    // accesses); library-owned
     double* fscr;
     // ... and its HBM-streaming variant (windows whose per-step state does not fit the CU's LDS): per window the observations,
     // the sweep's uniforms, the state maps and the states, [W][stream_stride] bytes; library-owned
@@ -100,6 +101,9 @@ struct KernelParams {
     // that fits them, runs beside this one on its own stream).  One launch for everything: INT32_MIN / INT32_MAX
     int32_t t_lo, t_hi;
 };
+
+// pairs of pdf values per step in the scratch KernelParams::fscr
+__host__ __device__ constexpr int big_scratch_pairs(int K) { return (K + 1) / 2; }
 
 // bytes of one window's slab of KernelParams::sscr for `cap` = NT * L steps (observations | uniforms | maps | states + 8)
 __host__ __device__ inline size_t stream_slab_bytes(size_t cap) { return (cap * (8 + 8 + 4) + cap + 8 + 255) & ~(size_t)255; }

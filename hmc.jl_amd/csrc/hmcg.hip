@@ -284,8 +284,8 @@ struct Plan {
     int NT() const { return v ? v->NT : bv->NT; }
     int L() const { return v ? v->L : bigL; }
     int NH() const { return v ? v->NH : 0; }
-    // LDS-resident kernel: per-step pdfs handed from the product phase to the replay, [W][L][K][NT] doubles
-    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)K * (size_t)bv->NT : 0; }
+    // LDS-resident kernel: per-step pdfs handed from the product phase to the replay, [W][L][ceil(K/2)][NT][2] doubles
+    size_t scratch_bytes(int W, int K) const { return bv ? sizeof(double) * (size_t)W * (size_t)bigL * (size_t)(2 * hmcg::big_scratch_pairs(K)) * (size_t)bv->NT : 0; }
     // streaming form: per window the observations, uniforms, state maps and states of its NT * L steps
     size_t slab_bytes() const { return stream ? hmcg::stream_slab_bytes((size_t)bv->NT * (size_t)bigL) : 0; }
     size_t stream_bytes(int W) const { return slab_bytes() * (size_t)W; }

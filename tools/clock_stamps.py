@@ -4,7 +4,7 @@ clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the sweep loop (median 
 the phase table.  usage: python tools/clock_stamps.py [K=3] [T=1000] [W=256] [draws=1000] [warm_s=2.5]"""
 import os, sys, time
 os.environ.setdefault("HMCG_DIAG", "1")      # arms the library's diagnostic switches (read once at first use)
-os.environ["HMCG_LIB"] = "libhmcgibbs_stamps.so"
+os.environ.setdefault("HMCG_LIB", "libhmcgibbs_stamps.so")
 os.environ["HMCG_STAMPS_AFTER"] = "1000000"      # replaced below: the library reads it at its first launch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 3

@@ -2,7 +2,7 @@
 printed by the library).  usage: [HMCG_FLAVOUR=p1|p2|h] python tools/stamps.py [threads_per_window] [W] [T] [K]"""
 import os, sys
 os.environ.setdefault("HMCG_DIAG", "1")      # arms the library's diagnostic switches (read once at first use)
-os.environ["HMCG_LIB"] = "libhmcgibbs_stamps.so"
+os.environ.setdefault("HMCG_LIB", "libhmcgibbs_stamps.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hmc_jl_amd
 from hmc_jl_amd import synth
