@@ -50,7 +50,7 @@ struct BigShared {
     double fcM[2][K * K];         // forecast scratch (cooperative matrix power on the forecast wave)
     double fcv[2][K];
     double fcval[HMCG_MAXH];
-    double exptab[EXPTAB_N];      // 2^(j/N): the table of exp_tab (gibbs_device.hpp)
+    double exptab[EXPTAB_N * EXPTAB_C];   // 2^(j/N): the replicated table of exp_tab (gibbs_device.hpp)
     // signal path (SIG): signal steps by state, the pivoted sums over the signal positions, the last noisy observation of
     // the running sample (forecastsignal's `signal`) and the filtered probabilities at end_pos, by sweep parity
     unsigned cntm[NW][K];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     }
     (void)sb; (void)se; (void)tail; (void)kfac;
 
-    for (int i = tid; i < EXPTAB_N; i += NT) sh.exptab[i] = exp2((double)i * (1.0 / EXPTAB_N));
+    exptab_fill(sh.exptab, tid, NT);
     // ---- observations into LDS (coalesced), xi = mean(Y) (src/Hmc.jl:136; always the mean of the REAL window) ----
     bool bad = false;
     double part = 0.0;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const double z = (yv - th.mu[s]) * (th.isd[s] * kf);
-            fv[s] = exp_tab(-(z * z), sh.exptab) * (th.coef[s] * kf);
+            fv[s] = exp_tab(-(z * z), sh.exptab, lane & (EXPTAB_C - 1)) * (th.coef[s] * kf);
             hm = max(hm, (unsigned)__double2hiint(fv[s]));
         }
         {
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     HMCG_EACH ni[g][s] = (int)nn[g][s];
                     HMCG_SB;
 #pragma unroll
-                    HMCG_EACH tj[g][s] = sh.exptab[ni[g][s] & (EXPTAB_N - 1)];
+                    HMCG_EACH tj[g][s] = exptab_at(sh.exptab, ni[g][s], lane & (EXPTAB_C - 1));
                     HMCG_SB;
 #pragma unroll
                     HMCG_EACH r[g][s] = fma(-nn[g][s], EXPTAB_N == 64 ? 1.0830424693267560e-02 : 2.70760617331689e-03, x[g][s]);

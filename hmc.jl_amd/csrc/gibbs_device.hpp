@@ -150,16 +150,32 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 
 // exp(x), x <= 0, with a table of 2^(j/N) held in LDS: x = (N e + j) ln2/N + r, |r| <= ln2/(2N), exp(r) by a
 // Taylor polynomial, result 2^e * tab[j] * poly: ~1 ulp.  N = 64 with degree 5 (truncation 3.5e-17) or N = 256 with
-// degree 4 (3.8e-17).  256 entries are the default (one FMA less per exponential: +1.5 % on the headline kernel, +0.9 % at
-// K = 8; tools/ab.sh, tools/ab_shapes.sh); a translation unit may define HMCG_EXPTAB_N 64 ahead of this header -- the one that
-// holds the K = 3, 16-steps-per-thread variants does, because with 256 entries the backend's register-allocation fault
-//  strikes its capped flavour (16 spill stores ahead of an exec restore; isa_lint refuses the build).
+// degree 4 (3.8e-17).
+// The table is REPLICATED: EXPTAB_C copies, entry j of copy c at tab[j * EXPTAB_C + c], lane l reading copy l % EXPTAB_C.
+// Every lane looks up its own random j: out of ONE copy the 64 lanes of a ds_read_b64 collide ~6 deep on the 64 banks, and
+// all four waves of a window evaluate their pdfs at the same time -- the phase ran at 1.65x its issue floor on the LDS
+// pipe (round 4, tools/phase_table.py).  With 32 copies of a 64-entry table (16 KB) copy c owns banks 2c, 2c+1 whatever
+// j is, and lanes l, l + 32 go through the pipe in different halves: no conflict at all.  (256 entries x 32 copies would
+// be 64 KB; the 64-entry table costs one FMA more per exponential.)  A translation unit may define HMCG_EXPTAB_N /
+// HMCG_EXPTAB_COPIES ahead of this header (A/B builds only: every shipped kernel uses the same table).
 #ifndef HMCG_EXPTAB_N
-#define HMCG_EXPTAB_N 256
+#define HMCG_EXPTAB_N 64
 #endif
-constexpr int EXPTAB_N = HMCG_EXPTAB_N;
+#ifndef HMCG_EXPTAB_COPIES
+#define HMCG_EXPTAB_COPIES 32
+#endif
+constexpr int EXPTAB_N = HMCG_EXPTAB_N, EXPTAB_C = HMCG_EXPTAB_COPIES;
 static_assert(EXPTAB_N == 64 || EXPTAB_N == 256, "exp table: 64 or 256 entries");
-__device__ __forceinline__ double exp_tab(double x, const double* tab)
+static_assert(EXPTAB_C >= 1 && EXPTAB_C <= 64 && (EXPTAB_C & (EXPTAB_C - 1)) == 0, "copies: a power of two");
+// fills tab[EXPTAB_N * EXPTAB_C] (all threads of the block; the caller's next barrier publishes it)
+__device__ __forceinline__ void exptab_fill(double* tab, int tid, int nthreads)
+{
+    for (int i = tid; i < EXPTAB_N * EXPTAB_C; i += nthreads)
+        tab[i] = exp2((double)(i / EXPTAB_C) * (1.0 / EXPTAB_N));      // correctly rounded enough (OCML exp2, < 1 ulp)
+}
+// the table entry of exponent index ni for a lane whose copy is c = lane % EXPTAB_C
+__device__ __forceinline__ double exptab_at(const double* tab, int ni, int c) { return tab[(ni & (EXPTAB_N - 1)) * EXPTAB_C + c]; }
+__device__ __forceinline__ double exp_tab(double x, const double* tab, int c)
 {
     x = fmax(x, -746.0);
     double n, r, p;
@@ -176,7 +192,7 @@ __device__ __forceinline__ double exp_tab(double x, const double* tab)
         p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
     }
     const int ni = (int)n;
-    const double tj = tab[ni & (EXPTAB_N - 1)];
+    const double tj = exptab_at(tab, ni, c);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -706,7 +722,7 @@ struct SweepShared {
     double bred[NW];              // generic block reductions (init)
     double med[2];
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
-    double exptab[EXPTAB_N];      // 2^(j/N), j = 0..N-1
+    double exptab[EXPTAB_N * EXPTAB_C];   // 2^(j/N), j = 0..N-1, EXPTAB_C copies (entry j of copy c at [j * EXPTAB_C + c])
     // decoded output role of every lane of the (at most two) output waves, staged once per launch: slot 0 = the
     // parameter-output wave, slot 1 = the forecast wave when it is a different one
     struct OutConst { double* base; double yr; int packed; int h; };
@@ -773,6 +789,7 @@ __device__ __forceinline__ void sort_order(const double (&mu)[K], int (&order)[K
 #define STAMP(i)                                                          \
     do {                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                \
+        asm volatile("; HMCG_STAMP_MARK %0" :: "n"(i));                    \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
         __builtin_amdgcn_s_waitcnt(0xC07F);                               \
         __builtin_amdgcn_sched_barrier(0);                                \
@@ -825,7 +842,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         return;
     }
 
-    for (int i = tid; i < EXPTAB_N; i += NT + 64 * NH) sh.exptab[i] = exp2((double)i * (1.0 / EXPTAB_N));   // correctly rounded enough (OCML exp2, < 1 ulp)
+    exptab_fill(sh.exptab, tid, NT + 64 * NH);
     // ---- load the window's observations (once per launch) ----
     // Steps at or beyond T ("padded": t0 + l >= T) carry the pseudo-state XPAD.  For K <= 3 that is the out-of-range value K,
     // which no `x == i` test matches and which the backward pass keeps in place by itself (the maps beyond T-1 are the
@@ -1666,26 +1683,100 @@ void gibbs_sweeps_kernel(const KernelParams p)
         // ---- forward filter (:371-440) as a scan of M_t = A diag(f_t) ----
         double f[L][K];
         unsigned und = 0;                            // bit l: every pdf of step l underflowed
+        {
+            // The L K emission values in blocks of up to 16, ONE OPERATION AT A TIME across the block (a sched_barrier after
+            // each): the instances of an operation are independent, so they issue back to back, and all the block's table reads
+            // are in flight together.  Same operations per value as exp_tab: same bits.
+            constexpr int LB = (16 / K) < L ? (16 / K) : L;          // steps per block
+#define HMCG_EACH for (int g = 0; g < LB; ++g) _Pragma("unroll") for (int s = 0; s < K; ++s)
+#define HMCG_SB __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            unsigned hm = 0;
+            for (int l0 = 0; l0 < L; l0 += LB) {
+                double x[LB][K], nn[LB][K], tj[LB][K], r[LB][K], pp[LB][K];
+                int ni[LB][K];
+                auto LL = [&](int g) __attribute__((always_inline)) { return l0 + g < L ? l0 + g : L - 1; };
+                auto issig = [&](int g) __attribute__((always_inline)) { return SIG && (t0 + LL(g)) >= sb && (t0 + LL(g)) < se; };
+                HMCG_SB;
 #pragma unroll
-            for (int s = 0; s < K; ++s) {
-                double z = (y[l] - mu[s]) * isd[s];          // isd holds 1/(sd*sqrt(2)): exp(-z^2) = exp(-((y-mu)/sd)^2/2)
-                double cf = coef[s];
-                if constexpr (SIG) {                 // signal positions: sd scaled by (1 + kappa) (:382, quirk 4)
-                    const bool issig = (t0 + l) >= sb && (t0 + l) < se;
-                    z = issig ? z * kfac : z;
-                    cf = issig ? cf * kfac : cf;
+                HMCG_EACH x[g][s] = y[LL(g)] - mu[s];
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH x[g][s] = x[g][s] * isd[s];
+                if constexpr (SIG) {
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH x[g][s] = issig(g) ? x[g][s] * kfac : x[g][s];
                 }
-                f[l][s] = exp_tab(-(z * z), sh.exptab) * cf;
-                hm = max(hm, (unsigned)__double2hiint(f[l][s]));
-            }
-            // exact power-of-two scaling of the step: largest pdf into [0.5,1)
-            const int e = 1022 - (int)(hm >> 20);
+                HMCG_SB;
 #pragma unroll
-            for (int s = 0; s < K; ++s) f[l][s] = ldexp(f[l][s], e);
-            und |= (hm < 0x01A56E1Fu) ? (1u << l) : 0u;     // largest pdf < 1e-300 (high word of 1e-300 is 0x01A56E1F)
+                HMCG_EACH x[g][s] = -(x[g][s] * x[g][s]);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH x[g][s] = fmax(x[g][s], -746.0);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH nn[g][s] = x[g][s] * (EXPTAB_N == 64 ? 92.332482616893657 : 369.3299304675746);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH nn[g][s] = rint(nn[g][s]);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH ni[g][s] = (int)nn[g][s];
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH tj[g][s] = exptab_at(sh.exptab, ni[g][s], lane & (EXPTAB_C - 1));
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH r[g][s] = fma(-nn[g][s], EXPTAB_N == 64 ? 1.0830424693267560e-02 : 2.70760617331689e-03, x[g][s]);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH r[g][s] = fma(-nn[g][s], EXPTAB_N == 64 ? 2.9815858269852933e-12 : 7.453964567463233e-13, r[g][s]);
+                HMCG_SB;
+                if constexpr (EXPTAB_N == 64) {
+#pragma unroll
+                    HMCG_EACH pp[g][s] = fma(r[g][s], 1.0 / 120.0, 1.0 / 24.0);
+                    HMCG_SB;
+#pragma unroll
+                    HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 1.0 / 6.0);
+                } else {
+#pragma unroll
+                    HMCG_EACH pp[g][s] = fma(r[g][s], 1.0 / 24.0, 1.0 / 6.0);
+                }
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 0.5);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 1.0);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH pp[g][s] = fma(pp[g][s], r[g][s], 1.0);
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH pp[g][s] = tj[g][s] * pp[g][s];
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH pp[g][s] = ldexp(pp[g][s], ni[g][s] >> (EXPTAB_N == 64 ? 6 : 8));
+                HMCG_SB;
+#pragma unroll
+                HMCG_EACH pp[g][s] = pp[g][s] * (issig(g) ? coef[s] * kfac : coef[s]);
+                HMCG_SB;
+#pragma unroll
+                for (int g = 0; g < LB; ++g) {
+                    if (l0 + g < L) {
+                        unsigned hm = 0;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) hm = max(hm, (unsigned)__double2hiint(pp[g][s]));
+                        const int e = 1022 - (int)(hm >> 20);
+#pragma unroll
+                        for (int s = 0; s < K; ++s) f[l0 + g][s] = ldexp(pp[g][s], e);
+                        und |= (hm < 0x01A56E1Fu) ? (1u << (l0 + g)) : 0u;
+                    }
+                }
+                HMCG_SB;
+            }
+#undef HMCG_EACH
+#undef HMCG_SB
         }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(und != 0u) != 0ull, 0)) {
             // (rare, wave-uniform branch) every pdf of some step underflowed: treat the observation as missing (f = 1)

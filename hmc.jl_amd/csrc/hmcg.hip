@@ -938,8 +938,13 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         p.final_launch = (ch.s1 == total_sweeps) ? 1 : 0;
         const size_t ndc = (size_t)(ch.d1 - ch.d0);
         p.nd_ld = (int32_t)std::max<size_t>(ndc, 1); p.draw_off = (int32_t)ch.d0;
+        // The LAST chunk's draws (1/32 of the run, 1.3 MB at the headline shape) are written by the kernel straight into the
+        // pinned staging buffer: host memory the device addresses directly, complete at the end of the kernel -- there is no
+        // copy behind the last kernel (it cost ~0.1 ms of the call's tail: nothing left to hide it behind).
+        const bool direct_tail = stream_draws && copy_out && cidx == nch - 1 && !want_corr && nch > 1 &&
+                                 diag_env("HMCG_NO_TAIL_COPY") == nullptr && diag_env("HMCG_NO_DIRECT_TAIL") == nullptr;
         if (stream_draws) {
-            double* cb = DP(double, o_dchunk[slot]);
+            double* cb = direct_tail ? PP(double, o_pchunk[slot]) : DP(double, o_dchunk[slot]);
             p.mu = cols[0].ncol ? cb + ndc * cols[0].off * N : nullptr;
             p.sig2 = cols[1].ncol ? cb + ndc * cols[1].off * N : nullptr;
             p.A = cols[2].ncol ? cb + ndc * cols[2].off * N : nullptr;
@@ -965,7 +970,9 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             // skips are decided in the first launch's prologue: its status words travel with the first chunk, so that the
             // scatter knows which windows' blocks hold nothing
             if (cidx == 0 && copy_out) HIP_TRY(hipMemcpyAsync(P + o_pst0, D + o_dst, 4 * N, hipMemcpyDeviceToHost, cs));
-            if (ndc > 0 && copy_out)
+            // (one engine's D2H rate, not the PCIe link, bounds a copy: 12 GB/s on the slowest box seen -- there the first
+            //  chunk's 20 MB take 1.7 ms; splitting a chunk over two copy streams changed nothing, measured)
+            if (ndc > 0 && copy_out && !direct_tail)
                 HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, cs));
             HIP_TRY(hipEventRecord(c.evc[slot], cs));
             if (want_corr && ndc > 0) {

@@ -1,8 +1,7 @@
-// base-path kernels, K = 3, 16 steps per thread (windows of 2049..4096 steps), in a translation unit of their own: with the
-// 256-entry exp table the capped flavour <3,16,256,...,0,2> comes out of the backend with register spills placed ahead of a
-// join block's exec restore (the fault of DESIGN.md section 5a; tools/isa_lint.py refuses it, `make repro-exptab256` shows
-// it), with the 64-entry table it does not -- so these three keep the smaller table.
-#define HMCG_EXPTAB_N 64
+// base-path kernels, K = 3, 16 steps per thread (windows of 3073..4096 steps), in a translation unit of their own (they are
+// the slowest instantiations to compile).  Until round 3 this unit kept a 64-entry exp table while every other kernel had
+// 256 entries (the backend's register-allocation fault of DESIGN.md section 5a struck its capped flavour with the larger
+// one); since round 4 every kernel uses the same replicated 64-entry table (gibbs_device.hpp, exp_tab).
 #include <hip/hip_runtime.h>
 #include "variants.hpp"
 namespace hmcg_host {

@@ -85,13 +85,13 @@ def test_every_variant_against_oracle(hmclib, oracle, monkeypatch, K, L, path, f
             assert np.max(np.abs(g["pi_smooth_mean"][w, :T] - o["pi_smooth"].mean(axis=0))) < TOL
 
 
-@pytest.mark.parametrize("T", [2049, 3000, 4096])
+@pytest.mark.parametrize("T", [2049, 3000, 3073, 4096])
 def test_k3_sixteen_steps_per_thread_lengths(hmclib, oracle, T):
-    """K = 3, T in 2049..4096: the L = 16 register-resident kernels (the table prefers the plain flavour there),
-    default dispatch, longer chain than the per-variant sweep above."""
+    """K = 3, T in 2049..4096: the L = 12 (T <= 3072) and L = 16 register-resident kernels, default dispatch, longer chain
+    than the per-variant sweep above; the second window (500 steps shorter) may fall into the class below: bucketed."""
     Y, Tw, fut = synth.generate_panel(2, T, 3, ragged=[T, T - 500])
     g = _lib.estimate_batch_host(Y, Tw, 3, 3, 12, (12,), fut[:, 11:12], want_state=True)
-    assert g["steps_per_thread"] == 16
+    assert g["steps_per_thread"] == (12 if T <= 3072 else 16)
     for w in range(2):
         o = oracle.estimate_window(Y[w, :Tw[w]], 3, 3, 12, (12,), fut[w, 11:12], window_id=w)
         assert np.array_equal(g["x_final"][w, :Tw[w]], o["x_final"])
@@ -202,7 +202,7 @@ def test_smoothed_means_beyond_the_lds(hmclib, oracle, K, T):
     Y, Tw, fut = synth.generate_panel(1, T, K)
     g = _lib.estimate_batch_host(Y, Tw, K, 1, 3, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
     o = oracle.estimate_window(Y[0], K, 1, 3, (12,), fut[0, 11:12], window_id=0, want_smooth=True)
-    assert g["status"][0] == o["status"] == 0 and g["lds_bytes"] < 32 * 1024
+    assert g["status"][0] == o["status"] == 0 and g["lds_bytes"] < 48 * 1024      # the static part only: no per-step arrays in the LDS
     assert np.array_equal(g["x_final"][0], o["x_final"])
     assert np.max(np.abs(g["pi_smooth_mean"][0] - o["pi_smooth"].mean(axis=0))) < TOL
     assert close(g["mu"][0].T, o["mu"]) < TOL and close(g["pif_final"][0], o["pif_final"]) < TOL

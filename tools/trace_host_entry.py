@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, T, K, DRAWS = 256, 1000, 3, 1000
 Y, Tw, fut = synth.generate_panel(W, T, K)
 yreal = fut[:, 11:12]
-hd = [0x484d4347, 3, W, K, T, 0, DRAWS, 1, 12, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0]
+hd = [0x484d4347, 3, W, K, T, 0, DRAWS, 1, 12, 0, 0, 0, 0, 0, 0, 0, 0, 0, int(os.environ.get("TRACE_CALLS", "8")), 0]
 with tempfile.TemporaryDirectory() as tmp:
     req = os.path.join(tmp, "req.bin")
     with open(req, "wb") as f:
