@@ -673,7 +673,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const double z = (yv - th.mu[s]) * (th.isd[s] * kf);
-            fv[s] = exp_tab(-(z * z), sh.exptab, lane & (EXPTAB_C - 1)) * (th.coef[s] * kf);
+            fv[s] = exp_tab<true>(-(z * z), sh.exptab, lane & (EXPTAB_C - 1)) * (th.coef[s] * kf);
             hm = max(hm, (unsigned)__double2hiint(fv[s]));
         }
         {
@@ -921,13 +921,10 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     HMCG_EACH x[g][s] = fmax(x[g][s], -746.0);
                     HMCG_SB;
 #pragma unroll
-                    HMCG_EACH nn[g][s] = x[g][s] * (EXPTAB_N == 64 ? 92.332482616893657 : 369.3299304675746);
+                    HMCG_EACH nn[g][s] = fma(x[g][s], EXPTAB_N == 64 ? 92.332482616893657 : 369.3299304675746, EXP_MAGIC);    // exp_tab<true>
                     HMCG_SB;
 #pragma unroll
-                    HMCG_EACH nn[g][s] = rint(nn[g][s]);
-                    HMCG_SB;
-#pragma unroll
-                    HMCG_EACH ni[g][s] = (int)nn[g][s];
+                    HMCG_EACH { ni[g][s] = __double2loint(nn[g][s]); nn[g][s] = nn[g][s] - EXP_MAGIC; }
                     HMCG_SB;
 #pragma unroll
                     HMCG_EACH tj[g][s] = exptab_at(sh.exptab, ni[g][s], lane & (EXPTAB_C - 1));
@@ -1136,6 +1133,59 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         //  time -- 64 more live doubles were measured to land in AGPRs and cost four times the instructions of the reads.)
         {
             const bool want_pif = (last_sweep || do_smooth) && p.pif_final != nullptr;
+#ifndef HMCG_BIG_NO_ASM
+            constexpr bool ASM_REPLAY = K == 8 && !SM && !SIG && !STREAM;
+#else
+            constexpr bool ASM_REPLAY = false;
+#endif
+            bool replay_done = false;
+#ifdef HMCG_REPLAY_CHECK
+            double av_asm[K] = {}, chk_pie = 0.0;
+            uint32_t chk_maps = 0;
+            int st_asm = 0;
+#endif
+            if constexpr (ASM_REPLAY) {
+                if (!want_pif) {
+                    // K = 8, every sweep that does not also hand out pif per step: the whole loop as one hand-scheduled assembly
+                    // statement (tools/gen_replay_asm.py: the same operations in the same order, bit-identical; ~290
+                    // instructions per step instead of 384 -- no selects in the categorical count, A in registers)
+                    typedef __attribute__((address_space(3))) const void lds_cvoid;
+                    const int own_t = (T - 1) / L;
+                    const double* asm_fb = fscr_w;
+                    const uint32_t asm_voff = (uint32_t)threadIdx.x * 16u;
+                    const uint32_t asm_lds = (uint32_t)(uintptr_t)(lds_cdouble*)&th.A[0][0];
+                    const uint32_t asm_au = (uint32_t)(uintptr_t)(lds_cvoid*)&uxs[t0 >= 1 ? t0 - 1 : 0];
+                    const uint32_t asm_am = (uint32_t)(uintptr_t)(lds_cvoid*)&maps[t0 >= 1 ? t0 - 1 : 0];
+                    const uint32_t asm_incu = t0 >= 1 ? 8u : 0u, asm_incm = t0 >= 1 ? 4u : 0u;
+                    const int asm_ownw = __builtin_amdgcn_readfirstlane((own_t >> 6) == wave_u ? 1 : 0);
+                    const int asm_lown = tid == own_t ? (T - 1) - own_t * L : -1;
+                    const uint32_t asm_pie = (uint32_t)(uintptr_t)(lds_cvoid*)&th.pi_end[0];
+                    const int asm_flag = HMCG_ST_EMIS_UNDERFLOW;
+                    int asm_l, asm_t, asm_u;
+#ifdef HMCG_REPLAY_CHECK                              // (debug: the assembly loop first, then the C++ loop from the same state; differences -> status bits)
+                    double av_in[K];
+                    const int st_in = st;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) av_in[s] = av[s];
+#endif
+#include "replay_asm_k8.inc"
+                    (void)asm_l; (void)asm_t; (void)asm_u;
+                    if (tid == own_t) sh.ulast = uxs[T - 1];
+#ifdef HMCG_REPLAY_CHECK
+                    __syncthreads();
+                    for (int l = 0; l < L; ++l) chk_maps ^= (t0 + l >= 1 && t0 + l < T) ? maps[t0 + l - 1] * (uint32_t)(2 * l + 1) : 0u;
+                    chk_pie = 0.0;
+                    if (tid == own_t) { for (int s = 0; s < K; ++s) chk_pie += th.pi_end[s] * (s + 1); }
+#pragma unroll
+                    for (int s = 0; s < K; ++s) { av_asm[s] = av[s]; av[s] = av_in[s]; }
+                    st_asm = st; st = st_in;
+                    __syncthreads();
+#else
+                    replay_done = true;
+#endif
+                }
+            }
+            if (!replay_done) {
             double fnext[K];                     // pdfs of the step ahead, on their way from the scratch
 #pragma unroll
             for (int s = 0; s < K; ++s) fnext[s] = fscr[fslot(0, s, threadIdx.x)];
@@ -1320,6 +1370,26 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                     }
                 }
             }
+            }   // (!replay_done)
+#ifdef HMCG_REPLAY_CHECK
+            if constexpr (ASM_REPLAY) {
+                if (!want_pif) {
+                    __syncthreads();
+                    uint32_t m2 = 0;
+                    for (int l = 0; l < L; ++l) m2 ^= (t0 + l >= 1 && t0 + l < T) ? maps[t0 + l - 1] * (uint32_t)(2 * l + 1) : 0u;
+                    bool bad_av = false;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) bad_av |= __double_as_longlong(av_asm[s]) != __double_as_longlong(av[s]);
+                    double pie2 = 0.0;
+                    if (tid == (T - 1) / L) { for (int s = 0; s < K; ++s) pie2 += th.pi_end[s] * (s + 1); }
+                    if (bad_av) st |= 0x100;
+                    if (st_asm != (st & 0xFF)) st |= 0x200;
+                    if (m2 != chk_maps) st |= 0x400;
+                    if (tid == (T - 1) / L && pie2 != chk_pie) st |= 0x800;
+                    __syncthreads();
+                }
+            }
+#endif
         }
         if (tid == NT - 1) maps[cap - 1] = map_identity<K>();
         STAMP(7);

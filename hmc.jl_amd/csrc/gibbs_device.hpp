@@ -173,25 +173,42 @@ __device__ __forceinline__ void exptab_fill(double* tab, int tid, int nthreads)
     for (int i = tid; i < EXPTAB_N * EXPTAB_C; i += nthreads)
         tab[i] = exp2((double)(i / EXPTAB_C) * (1.0 / EXPTAB_N));      // correctly rounded enough (OCML exp2, < 1 ulp)
 }
-// the table entry of exponent index ni for a lane whose copy is c = lane % EXPTAB_C
-__device__ __forceinline__ double exptab_at(const double* tab, int ni, int c) { return tab[(ni & (EXPTAB_N - 1)) * EXPTAB_C + c]; }
+// the table entry of exponent index ni for a lane whose copy is c = lane % EXPTAB_C (byte address = entry << log2(8 C) | 8 c:
+// one v_and and one v_lshl_or)
+__device__ __forceinline__ double exptab_at(const double* tab, int ni, int c)
+{
+    const unsigned off = ((unsigned)(ni & (EXPTAB_N - 1)) * (unsigned)(8 * EXPTAB_C)) | ((unsigned)c * 8u);
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + off);
+}
+// MAGIC: n = x N/ln2 rounded to an integer by ONE fused add of 1.5 * 2^52 -- the integer is then the low word of the sum as
+// it stands (no v_rndne, no v_cvt) and n one subtraction away.  One instruction less per value where the table address
+// costs the same either way: +0.7 % on the K = 8 kernel (the LDS-resident kernels use it), -0.4 % on the K = 3 headline
+// kernel, whose compiler-chosen address arithmetic grows by one instruction (the register-resident kernels do not).
+constexpr double EXP_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: x + EXP_MAGIC holds round(x) in its low word, |x| < 2^31
+template <bool MAGIC = false>
 __device__ __forceinline__ double exp_tab(double x, const double* tab, int c)
 {
     x = fmax(x, -746.0);
     double n, r, p;
+    int ni;
+    if constexpr (MAGIC) {
+        const double t2 = fma(x, EXPTAB_N == 64 ? 92.332482616893657 : 369.3299304675746, EXP_MAGIC);
+        ni = __double2loint(t2);
+        n = t2 - EXP_MAGIC;
+    } else {
+        n = rint(x * (EXPTAB_N == 64 ? 92.332482616893657 : 369.3299304675746));      // N / ln 2
+        ni = (int)n;
+    }
     if constexpr (EXPTAB_N == 64) {
-        n = rint(x * 92.332482616893657);                     // 64 / ln 2
         r = fma(-n, 1.0830424693267560e-02, x);               // ln2/64 high part
         r = fma(-n, 2.9815858269852933e-12, r);               // ln2/64 low part
         p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
         p = fma(p, r, 1.0 / 6.0);
     } else {
-        n = rint(x * 369.3299304675746);                      // 256 / ln 2
         r = fma(-n, 2.70760617331689e-03, x);                 // ln2/256 high part
         r = fma(-n, 7.453964567463233e-13, r);                // ln2/256 low part
         p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
     }
-    const int ni = (int)n;
     const double tj = exptab_at(tab, ni, c);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);

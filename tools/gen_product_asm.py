@@ -28,14 +28,15 @@ What the loop costs: 576 fp64 + 32 LDS + 4 VMEM + ~24 scalar / wait instructions
 Registers: v[0:127] Q (outputs), v[128:191] accumulators, v[192:223] A rows 4..7, v[224:239] f, v240-v243 temporaries,
 s[36:99] A rows 0..3.
 """
+import os
 import sys
 
 TEST_NOLDS = "--test-nolds" in sys.argv        # timing experiments only (wrong results): no LDS reads / no scratch loads in the loop
 TEST_NOFV = "--test-nofv" in sys.argv
 IN_LOOP = False
 K = 8
-NSR = 4                                   # rows of A held in scalar registers (s[SBASE : SBASE + 16 NSR))
-SBASE = 36
+NSR = int(os.environ.get("PRODUCT_NSR", "4"))      # rows of A held in scalar registers (s[SBASE : SBASE + 16 NSR)); 4 measured best
+SBASE = 100 - 16 * NSR
 QREG = lambda i: "v[%d:%d]" % (2 * i, 2 * i + 1)
 ACC = lambda j: "v[%d:%d]" % (128 + 2 * j, 129 + 2 * j)
 AB = lambda b, s: "v[%d:%d]" % (192 + 16 * b + 2 * s, 193 + 16 * b + 2 * s)
@@ -113,58 +114,45 @@ emit("s_nop 4")
 emit("v_mov_b32 %s, %%[voff]" % VOFF)
 emit("s_waitcnt vmcnt(0)")                                   # the pdf pass's stores to the scratch have landed
 load_f(0, FV4)                                               # f of step 0
-# rows 0..NSR-1 of A: through the accumulator registers into scalar registers, for the whole loop
+# rows 0..NSR-1 of A: through the accumulator registers (and, beyond four rows, the buffers) into scalar registers
+STAGE = lambda i: 128 + i if i < 64 else 192 + (i - 64)      # v[128:191], then v[192:207]
 for k in range(NSR):
     for h in range(4):
-        emit("ds_read_b128 v[%d:%d], %%[lds] offset:%d" % (128 + 16 * k + 4 * h, 131 + 16 * k + 4 * h, 64 * k + 16 * h))
-read_row(0, 4)
-read_row(1, 5)
-emit("s_waitcnt lgkmcnt(8)")
+        emit("ds_read_b128 v[%d:%d], %%[lds] offset:%d" % (STAGE(16 * k + 4 * h), STAGE(16 * k + 4 * h) + 3, 64 * k + 16 * h))
+emit("s_waitcnt lgkmcnt(0)")
 for i in range(16 * NSR):
-    emit("v_readfirstlane_b32 s%d, v%d" % (SBASE + i, 128 + i))
+    emit("v_readfirstlane_b32 s%d, v%d" % (SBASE + i, STAGE(i)))
 emit("s_waitcnt vmcnt(0)")                                   # f of step 0
 # Q = A diag(f_0): the product of the identity with M_0, exactly
 for r in range(NSR):
     for s in range(K):
         emit("v_mul_f64 %s, %s, %s" % (QREG(r * K + s), AS(r, s), FV(s)))
-emit("s_waitcnt lgkmcnt(0)")
-for s in range(K):
-    emit("v_mul_f64 %s, %s, %s" % (QREG(4 * K + s), AB(0, s), FV(s)))
-for s in range(K):
-    emit("v_mul_f64 %s, %s, %s" % (QREG(5 * K + s), AB(1, s), FV(s)))
-read_row(0, 6)
-read_row(1, 7)
-emit("s_waitcnt lgkmcnt(0)")
-for s in range(K):
-    emit("v_mul_f64 %s, %s, %s" % (QREG(6 * K + s), AB(0, s), FV(s)))
-for s in range(K):
-    emit("v_mul_f64 %s, %s, %s" % (QREG(7 * K + s), AB(1, s), FV(s)))
+for r in range(NSR, K):
+    read_row(r & 1, r)
+    emit("s_waitcnt lgkmcnt(0)")
+    for s in range(K):
+        emit("v_mul_f64 %s, %s, %s" % (QREG(r * K + s), AB(r & 1, s), FV(s)))
 emit("s_mov_b32 %[l], 1")
 emit("s_cmp_lt_u32 1, %[L]")
 emit("s_cbranch_scc0 .Lhmcg_prod_done_%=")
 load_f(1, FV4)                                               # f of step 1
-read_row(0, 4)                                               # rows 4, 5 of the first block
-read_row(1, 5)
+read_row(0, NSR)                                             # stream positions 0 and 1
+read_row(1, NSR + 1 % (K - NSR))
 
 
 def step_body(slot):
-    """one step (`slot` only numbers the labels)"""
+    """one step (`slot` only numbers the labels).  The rows NSR..7 of A form a cyclic stream through the two LDS buffers:
+    stream position p (row NSR + p mod n) sits in buffer p & 1 and is requested two positions ahead, right after the
+    multiply-adds of position p - 2 have been issued; a step is 2 n positions (even: the pattern repeats every step)."""
+    n = K - NSR
     for b in range(2):
-        for k in range(NSR):                                 # rows 0..3: scalar operands, nothing to wait for
+        for k in range(NSR):                                 # scalar operands: nothing to wait for
             fma_row(b, k, lambda s, k=k: AS(k, s))
-        # rows 4..7 through the two LDS buffers; every read is requested three rows ahead
-        emit("s_waitcnt lgkmcnt(4)")                         # row 4 (row 5 may still be on its way)
-        fma_row(b, 4, lambda s: AB(0, s))
-        read_row(0, 6)
-        emit("s_waitcnt lgkmcnt(4)")                         # row 5
-        fma_row(b, 5, lambda s: AB(1, s))
-        read_row(1, 7)
-        emit("s_waitcnt lgkmcnt(4)")                         # row 6
-        fma_row(b, 6, lambda s: AB(0, s))
-        read_row(0, 4)                                       # for the next block (or step; after the last one: drained below)
-        emit("s_waitcnt lgkmcnt(4)")                         # row 7
-        fma_row(b, 7, lambda s: AB(1, s))
-        read_row(1, 5)
+        for i in range(n):
+            pos = b * n + i
+            emit("s_waitcnt lgkmcnt(4)")                     # this position's row (the next one may still be on its way)
+            fma_row(b, NSR + i, lambda s, pos=pos: AB(pos & 1, s))
+            read_row(pos & 1, NSR + (pos + 2) % n)           # two positions ahead (after the last step: drained below)
         if b == 0:
             emit("s_waitcnt vmcnt(0)")                       # this step's f (requested at the end of the previous step)
         for rr in range(4):
