@@ -90,7 +90,7 @@ def kernel_name(K_, tm, sig=False, smooth=False):
     """The instantiation that ran, as rocprofv3 names it (template arguments from the call's own timing record)."""
     if tm.occupancy == 0:          # the LDS-resident kernel: <K, NT, SM, STREAM, SIG>
         return "hmcg::gibbs_sweeps_kernel_big<%d,%d,%s,%s,%s>" % (K_, tm.threads_per_window, str(smooth).lower(),
-                                                                  str(tm.lds_bytes < 21 * tm.threads_per_window * tm.steps_per_thread).lower(), str(sig).lower())
+                                                                  str(bool(tm.streaming)).lower(), str(sig).lower())
     return "hmcg::gibbs_sweeps_kernel<%d,%d,%d,%s,%s,%d,%d>" % (
         K_, tm.steps_per_thread, tm.threads_per_window, str(sig).lower(), str(smooth).lower(), tm.helper_waves, tm.occupancy)
 

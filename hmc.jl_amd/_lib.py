@@ -55,7 +55,7 @@ class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int32), ("threads_per_window", C.c_int32),
                 ("steps_per_thread", C.c_int32), ("lds_bytes", C.c_int32), ("helper_waves", C.c_int32),
                 ("device", C.c_int32), ("call_ms", C.c_double), ("windows", C.c_int32), ("occupancy", C.c_int32),
-                ("buckets", C.c_int32), ("reserved", C.c_int32)]
+                ("buckets", C.c_int32), ("streaming", C.c_int32)]
 
 
 _LIB = None
@@ -283,6 +283,7 @@ def estimate_batch_host(Y, T, K, burnin, nrun, horizons=(12,), yreal=None, seed=
     out["helper_waves"] = tm.helper_waves
     out["launches"] = tm.launches
     out["buckets"] = tm.buckets
+    out["streaming"] = bool(tm.streaming)
     out["call_ms"] = max(t.call_ms for t in tms)
     out["per_device"] = [dict(device=t.device, windows=t.windows, kernel_ms=t.kernel_ms, call_ms=t.call_ms, launches=t.launches)
                          for t in tms]

@@ -43,6 +43,8 @@ struct BigShared {
     RngBuf<K> rb[2];
     double gval[NG];              // gamma variates of the running parameter phase
     double wtot[NW][KK];
+    double rtot[NW][4][KK];       // cooperative scan: the four 16-lane row totals of every wave
+    double ptmp[NW][2][KK];       // ... and the partial products on the way to the wave total
     uint32_t wmap[NW][2];         // per-wave composed state map, byte-per-entry in two words
     double ulast;
     double bred[NW];
@@ -1079,6 +1081,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         scan_level_rowwise<K, DPP_ROW_SHR4, 0xF>(Q, N);
         scan_level_rowwise<K, DPP_ROW_SHR8, 0xF>(N, Q);
         rescale_pow2<KK>(Q);
+#ifdef HMCG_BIG_FULL_SCAN                         // (A/B: the two upper scan levels as full K x K products in every lane, as until round 4)
         scan_level_rowwise<K, DPP_ROW_BCAST15, 0xA>(Q, N);
         scan_level_rowwise<K, DPP_ROW_BCAST31, 0xC>(N, Q);
         rescale_pow2<KK>(Q);
@@ -1086,6 +1089,41 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
 #pragma unroll
             for (int i = 0; i < KK; ++i) sh.wtot[wave][i] = Q[i];
         }
+#else
+        // The scan stops at the 16-lane rows (four DPP levels).  What the two upper levels produced -- 2 x K^3 multiply-adds in
+        // EVERY lane -- is needed in two much smaller forms only: the wave's total W = R0 R1 R2 R3 (for the later waves), and
+        // for the lanes of row j the vector u_j = v R0 ... R_{j-1} that enters the row (v: what enters the wave).  Both are
+        // products of the four row totals R_j, which the last lane of each row leaves in LDS: W by three COOPERATIVE K x K
+        // products (lane 8 r + c owns entry (r, c): K multiply-adds a product instead of K^3), the u_j after barrier Bc by three
+        // cooperative vector-matrix steps (lane c of every eight owns entry c), exactly as the cross-wave prefix is formed.
+        const int er = lane >> 3, ec = lane & 7;                 // the entry this lane owns in a cooperative product
+        const bool evalid = er < K && ec < K;
+        if ((lane & 15) == 15) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i) sh.rtot[wave][lane >> 4][i] = Q[i];
+        }
+        __builtin_amdgcn_wave_barrier();                         // (the row totals are read by the other lanes of this wave only)
+        {
+            auto coop = [&](const double* X, const double* Y) __attribute__((always_inline)) {
+                const int rr = evalid ? er : 0, cc2 = evalid ? ec : 0;
+                double acc = X[rr * K] * Y[cc2];
+#pragma unroll
+                for (int k = 1; k < K; ++k) acc = fma(X[rr * K + k], Y[k * K + cc2], acc);
+                return acc;
+            };
+            asm volatile("" ::: "memory");
+            double pe = coop(sh.rtot[wave][0], sh.rtot[wave][1]);
+            if (evalid) sh.ptmp[wave][0][er * K + ec] = pe;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            pe = coop(sh.ptmp[wave][0], sh.rtot[wave][2]);
+            if (evalid) sh.ptmp[wave][1][er * K + ec] = pe;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            pe = coop(sh.ptmp[wave][1], sh.rtot[wave][3]);
+            if (evalid) sh.wtot[wave][er * K + ec] = pe;
+        }
+#endif
         STAMP(5);
         __syncthreads();                                                     // Bc
         STAMP(6);
@@ -1109,6 +1147,26 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 for (int r = 1; r < K; ++r) acc = fma(__shfl(vc, g8 | r, 64), col[r], acc);
                 vc = acc;
             }
+#ifndef HMCG_BIG_FULL_SCAN
+            // u_j for the lanes of row j: three more steps of the same kind over this wave's row totals; a lane keeps the
+            // vector of its own row
+            {
+                const int row = lane >> 4;
+                double vrow = vc;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double col[K];
+#pragma unroll
+                    for (int r = 0; r < K; ++r) col[r] = sh.rtot[wave_u][j][r * K + cc];
+                    double acc = __shfl(vc, g8, 64) * col[0];
+#pragma unroll
+                    for (int r = 1; r < K; ++r) acc = fma(__shfl(vc, g8 | r, 64), col[r], acc);
+                    vc = acc;
+                    vrow = (row > j) ? vc : vrow;
+                }
+                vc = vrow;
+            }
+#endif
 #pragma unroll
             for (int s = 0; s < K; ++s) av[s] = __shfl(vc, g8 | s, 64);
         }
@@ -1119,7 +1177,11 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 double acc = 0.0;
 #pragma unroll
                 for (int r = 0; r < K; ++r)
+#ifdef HMCG_BIG_FULL_SCAN
                     acc = fma(av[r], dpp_f64<DPP_WAVE_SHR1, 0xF>((r == s) ? 1.0 : 0.0, Q[r * K + s]), acc);
+#else
+                    acc = fma(av[r], dpp_f64<DPP_ROW_SHR1, 0xF>((r == s) ? 1.0 : 0.0, Q[r * K + s]), acc);   // the row's exclusive prefix
+#endif
                 nv[s] = acc;
             }
             rescale_pow2<K>(nv);

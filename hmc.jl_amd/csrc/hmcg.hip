@@ -519,7 +519,7 @@ void fill_timing(hmcg_timing* t, const Plan& pl, const DeviceCtx& c, double kern
     t->windows = windows;
     t->occupancy = pl.v ? pl.v->occ : 0;
     t->buckets = pl.nb > 1 ? pl.nb : 1;
-    t->reserved = 0;
+    t->streaming = pl.stream ? 1 : 0;
     t->lds_bytes = (int32_t)(static_lds_bytes(pl.fptr(), 0) + pl.dyn);
 }
 

@@ -95,7 +95,7 @@ struct hmcg_timing                    # include/hmcg.h (ABI 107)
     windows::Int32
     occupancy::Int32
     buckets::Int32
-    reserved::Int32
+    streaming::Int32
 end
 
 last_error() = unsafe_string(ccall((:hmcg_last_error, LIBHMCG), Cstring, ()))

@@ -193,7 +193,7 @@ typedef struct hmcg_timing {
                                 share a CU (the OCC template argument of the kernel that ran); 0 for the LDS-resident kernel */
     int32_t buckets;         /* length classes the call was dispatched in (1: one launch for every window); threads_per_window,
                                 steps_per_thread, helper_waves, occupancy and lds_bytes then describe the LONGEST class */
-    int32_t reserved;
+    int32_t streaming;       /* 1: the LDS-resident kernel ran in its HBM-streaming form (window longer than a CU's LDS holds) */
 } hmcg_timing;
 
 int hmcg_version(void);

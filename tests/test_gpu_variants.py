@@ -183,7 +183,7 @@ def test_smoothed_means_on_the_signal_path_lds_resident_kernel(hmclib, oracle, m
     g = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, (12,), fut[:, 11:12], want_state=True, sig_range=sig, save_range=sig,
                                  sigma_signal=ssig, kappa=0.6, n_samples=ns, alpha=2.0, nu=2.0, want_smooth=True, want_filter_mean=True)
     L = (T + 255) // 256
-    assert g["steps_per_thread"] == L and g["helper_waves"] == 0 and (g["lds_bytes"] < 21 * 256 * L) == stream
+    assert g["steps_per_thread"] == L and g["helper_waves"] == 0 and g["streaming"] == stream
     for w in range(2):
         Tn = int(Tw[w])
         o = oracle.estimate_signals(Y[w, :Tn], K, burnin, nrun, ns, sig=tuple(sig[w]), kappa=0.6, alpha=2.0, nu=2.0,
@@ -202,7 +202,7 @@ def test_smoothed_means_beyond_the_lds(hmclib, oracle, K, T):
     Y, Tw, fut = synth.generate_panel(1, T, K)
     g = _lib.estimate_batch_host(Y, Tw, K, 1, 3, (12,), fut[:, 11:12], want_state=True, want_smooth=True, want_filter_mean=True)
     o = oracle.estimate_window(Y[0], K, 1, 3, (12,), fut[0, 11:12], window_id=0, want_smooth=True)
-    assert g["status"][0] == o["status"] == 0 and g["lds_bytes"] < 48 * 1024      # the static part only: no per-step arrays in the LDS
+    assert g["status"][0] == o["status"] == 0 and g["streaming"]
     assert np.array_equal(g["x_final"][0], o["x_final"])
     assert np.max(np.abs(g["pi_smooth_mean"][0] - o["pi_smooth"].mean(axis=0))) < TOL
     assert close(g["mu"][0].T, o["mu"]) < TOL and close(g["pif_final"][0], o["pif_final"]) < TOL
