@@ -114,8 +114,15 @@ def shape_record(name, K_, lens, draws, reps=3, device=0):
            "kernel": kernel_name(K_, tm), "kernel_ms": k_ms, "value": W * draws / (k_ms * 1e-3), "unit": "Gibbs draws/s",
            "algorithmic_bytes_per_launch": by, "achieved_GBps": ach, "frac_of_8000": ach / HBM_PEAK_GBS,
            "frac_of_6300": ach / HBM_ACHIEVABLE_GBS, "steps_per_thread": tm.steps_per_thread,
-           "helper_waves": tm.helper_waves, "lds_bytes_per_window": tm.lds_bytes,
+           "helper_waves": tm.helper_waves, "lds_bytes_per_window": tm.lds_bytes, "length_buckets": tm.buckets,
            "windows_flagged": int((panel.status != 0).sum().item())}
+    if tm.buckets > 1:
+        # the same call as ONE launch sized for the longest window (no min_T hint: what every call did until round 3)
+        panel.run(burnin=0, bucketed=False)
+        one = float(np.mean([panel.run(burnin=0, bucketed=False) for _ in range(reps)]))
+        rec["single_launch_kernel_ms"] = one
+        rec["single_launch_value"] = W * draws / (one * 1e-3)
+        rec["kernel"] += " (+ %d shorter length classes side by side)" % (tm.buckets - 1)
     del panel
     return rec
 

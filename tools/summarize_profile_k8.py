@@ -13,7 +13,7 @@ os.makedirs(dst, exist_ok=True)
 K, T, W, SWEEPS = 8, 5000, 512, 1000
 ALGO = (T * (8 + 16 * K + 2) + 8 * (3 * K + K * K + 2)) * W * SWEEPS        # 690 720 B/draw
 L = (T + 255) // 256
-PDF_SCRATCH = 2 * 8 * L * K * 256 * W * SWEEPS                                # fscr[W][L][K][NT] written + read once per sweep
+PDF_SCRATCH = 3 * 8 * L * K * 256 * W * SWEEPS                                # fscr[W][L][K/2][NT][2]: written once, read twice per sweep (product, replay) since round 4
 
 
 def rows(pattern):
@@ -53,9 +53,8 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     out.update({"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                 "algorithmic_bytes_per_launch": ALGO, "pdf_scratch_bytes_per_launch_expected": PDF_SCRATCH,
                 "correction": "FETCH_SIZE (KB) x 1024 x 2: on gfx950 FETCH_SIZE counts 128-B requests at 64 B (guide, HBM section); the pdf "
-                              "scratch is read with 8 B/lane coalesced loads (512 B per wave-instruction) -- a width the guide lists as "
-                              "uncalibrated; the doubled figure equals the written bytes, which is what this scratch must give "
-                              "(written once, read once). WRITE_SIZE (KB) x 1024 is exact for streaming stores. Fabric-side counters: "
+                              "scratch is read with 16 B/lane coalesced loads (1 KB per wave-instruction), twice per sweep since round 4 "
+                              "(chunk product and replay; written once): the doubled figure should be about twice the written bytes. WRITE_SIZE (KB) x 1024 is exact for streaming stores. Fabric-side counters: "
                               "Infinity-Cache hits are included."})
     if out["rocprof_kernel_avg_ms"]:
         out["fabric_GBps"] = (fetch + write) / (out["rocprof_kernel_avg_ms"] * 1e-3) / 1e9

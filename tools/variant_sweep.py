@@ -55,13 +55,13 @@ def time_one(K, T, W, path, flavour, n):
 rows = []
 for path, Ks in (("base", (2, 3, 4)), ("sig", (2, 3, 4)), ("smooth", (2, 3, 4))):
     for K in Ks:
-        for L in (1, 2, 4, 8, 16):
-            if (L == 16 and not (K == 3 and path == "base")) or (L == 8 and K != 3 and path != "base"):
-                continue
+        Ls = {("base", 3): (1, 2, 3, 4, 6, 8, 12, 16), ("base", 2): (1, 2, 3, 4, 8), ("base", 4): (1, 2, 3, 4, 8), ("sig", 3): (1, 2, 3, 4, 8),
+              ("smooth", 3): (1, 2, 4, 8)}.get((path, K), (1, 2, 4))
+        for L in Ls:
             T = 256 * L - 24
             line = "%-6s K=%d L=%-2d T=%-4d" % (path, K, L, T)
             for W in (256, 2048):
-                n = draws if W == 256 else max(draws // 4, 20)
+                n = draws if W == 256 else max(draws // 2, 20)
                 res = {}
                 for fl in ("p1", "p2", "h"):
                     ms, nh = time_one(K, T, W, path, fl, n)
