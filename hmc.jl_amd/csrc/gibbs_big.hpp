@@ -135,7 +135,7 @@ __device__ __forceinline__ double uniform_f64(double v)
 template <bool GLOBAL, class T> struct StepPtr { using type = T*; };
 template <class T> struct StepPtr<true, T> { using type = __attribute__((address_space(1))) T*; };
 
-// STREAM: the window is longer than the CU's LDS holds (T beyond ~6 500 at K = 8, ~7 500 at K = 3): Y, the sweep's uniforms,
+// STREAM: the window is longer than the CU's LDS holds (T beyond ~5 500 at K = 8, ~6 000 at K = 3): Y, the sweep's uniforms,
 // the state maps and the states stream through HBM / L2 (each lane walks its own L consecutive steps, so a cache line
 // serves eight of them); slower per step than the LDS-resident form, but no longer refused (the reference's loops are
 // unbounded in N, src/Hmc.jl:406).
