@@ -178,7 +178,7 @@ emit(".Lhmcg_prod_done_%=:")
 emit("s_waitcnt vmcnt(0) lgkmcnt(0)")                        # the ring's loads and the rows requested ahead of steps that do not come
 emit("s_nop 4")                                              # ... nothing of ours is in flight when the compiler's code resumes
 
-path = "hmc.jl_amd/csrc/product_asm_k8.inc"
+path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hmc.jl_amd", "csrc", "product_asm_k8.inc")
 if TEST_NOLDS or TEST_NOFV:
     path = "/tmp/t/product_asm_test.inc"
 with open(path, "w") as f:

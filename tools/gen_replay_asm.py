@@ -24,6 +24,7 @@ Registers: v[0:15] av (in/out), v[16:79] A rows 4..7, v[80:95] nv, v[96:111] / v
 v[200:207] idx accumulators, v208.. temporaries; s[36:99] A rows 0..3, s[20:35] compare masks.
 """
 import os
+import sys
 EPS_FAST = os.environ.get("REPLAY_EPS_FAST", "0") == "1"     # min-of-eight fast path for the eps() guard: measured 0.8 % SLOWER (a dependent chain of seven v_min)
 K = 8
 SBASE = 36
@@ -221,7 +222,7 @@ emit(".Lhmcg_rep_done_%=:")
 emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
 emit("s_nop 4")
 
-path = "hmc.jl_amd/csrc/replay_asm_k8.inc"
+path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hmc.jl_amd", "csrc", "replay_asm_k8.inc")
 with open(path, "w") as f:
     f.write("// GENERATED by tools/gen_replay_asm.py -- do not edit.  The K = 8 filter replay as one asm statement.\n")
     f.write("asm volatile(\n")
