@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             // (K reads), gets the K entries of the vector by lane shuffles -- a step is K FMAs.  Same sums in the same order.
             const int c8 = lane & 7, g8 = lane & ~7;
             const int cc = c8 < K ? c8 : 0;
+#ifdef HMCG_BIG_SHFL_CHAIN                            // (A/B: the vector's entries fetched by eight lane shuffles a step, as until round 4)
             double vc = th.rho[cc];
             for (int ww = 0; ww < wave_u; ++ww) {
                 double col[K];
@@ -1147,6 +1148,42 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 for (int r = 1; r < K; ++r) acc = fma(__shfl(vc, g8 | r, 64), col[r], acc);
                 vc = acc;
             }
+            auto row_step = [&](int j) __attribute__((always_inline)) {
+                double col[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) col[r] = sh.rtot[wave_u][j][r * K + cc];
+                double acc = __shfl(vc, g8, 64) * col[0];
+#pragma unroll
+                for (int r = 1; r < K; ++r) acc = fma(__shfl(vc, g8 | r, 64), col[r], acc);
+                vc = acc;
+            };
+#else
+            // A step v <- v M with lane c of every eight owning entry c: the entries of v reach the lane by DPP ROTATIONS of the
+            // 16-lane row (both halves of a row hold the same eight entries, so row_ror:k hands lane c entry (c - k) mod 8) -- 14
+            // vector moves and 8 multiply-adds per step, nothing through LDS on the dependent chain (the 8 lane shuffles a step
+            // of the first version were 16 LDS round trips, ~1.2 k ticks a step on the last wave, which everyone waits for); the
+            // matrix entries M[(c - k) mod 8][c] each lane needs do not depend on v and are read ahead.
+            double vc = c8 < K ? th.rho[cc] : 0.0;
+            auto coop_step = [&](const double* Mm) __attribute__((always_inline)) {
+                double col[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = (c8 - k) & 7;
+                    col[k] = (r < K && c8 < K) ? Mm[(r < K ? r : 0) * K + cc] : 0.0;
+                }
+                double acc = vc * col[0];
+                acc = fma(dpp_f64<0x121, 0xF>(0.0, vc), col[1], acc);
+                acc = fma(dpp_f64<0x122, 0xF>(0.0, vc), col[2], acc);
+                acc = fma(dpp_f64<0x123, 0xF>(0.0, vc), col[3], acc);
+                acc = fma(dpp_f64<0x124, 0xF>(0.0, vc), col[4], acc);
+                acc = fma(dpp_f64<0x125, 0xF>(0.0, vc), col[5], acc);
+                acc = fma(dpp_f64<0x126, 0xF>(0.0, vc), col[6], acc);
+                acc = fma(dpp_f64<0x127, 0xF>(0.0, vc), col[7], acc);
+                vc = acc;
+            };
+            for (int ww = 0; ww < wave_u; ++ww) coop_step(sh.wtot[ww]);
+            auto row_step = [&](int j) __attribute__((always_inline)) { coop_step(sh.rtot[wave_u][j]); };
+#endif
 #ifndef HMCG_BIG_FULL_SCAN
             // u_j for the lanes of row j: three more steps of the same kind over this wave's row totals; a lane keeps the
             // vector of its own row
@@ -1155,13 +1192,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
                 double vrow = vc;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    double col[K];
-#pragma unroll
-                    for (int r = 0; r < K; ++r) col[r] = sh.rtot[wave_u][j][r * K + cc];
-                    double acc = __shfl(vc, g8, 64) * col[0];
-#pragma unroll
-                    for (int r = 1; r < K; ++r) acc = fma(__shfl(vc, g8 | r, 64), col[r], acc);
-                    vc = acc;
+                    row_step(j);
                     vrow = (row > j) ? vc : vrow;
                 }
                 vc = vrow;
