@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
     const int t0 = tid * L;
     int st = 0;
     if (T < 2 || T > cap || T > p.ldY) {
-        if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+        if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_T);
         return;
     }
 
@@ -196,13 +196,13 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
             bad_range |= svb < 0 || sve > T || (svb < sve && p.sigvals && sve - svb > p.nsave_ld);
         }
         if (bad_range) {
-            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_RANGE);
+            if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_RANGE);
             return;
         }
         if (sb >= se) { sb = T; se = T; }
         if (p.end_pos) tail = (T - 1) - p.end_pos[w];       // steps after the position whose smoothed probabilities are reported
         if (tail < 0 || tail > HMCG_MAXTAIL || tail > T - 1) {
-            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+            if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_T);
             return;
         }
     }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         part += v;
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
-        if (tid == 0) atomicOr(&p.status[w], HMCG_ST_NONFINITE);
+        if (tid == 0) flag_skipped(p, w, HMCG_ST_NONFINITE);
         return;
     }
     const double xi = block_sum<NW>(part, sh.bred, wave, lane) / (double)T;

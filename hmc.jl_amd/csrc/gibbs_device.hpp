@@ -100,7 +100,19 @@ struct KernelParams {
     // blocks of every other window leave at once (another launch of the same call, with the steps-per-thread variant
     // that fits them, runs beside this one on its own stream).  One launch for everything: INT32_MIN / INT32_MAX
     int32_t t_lo, t_hi;
+    // host entry, first launch of a call: pinned HOST memory (device-addressable), one word per window, zeroed by the host --
+    // a window the prologue skips puts its status bits here as well, so that the host knows whose block of a chunk buffer
+    // holds nothing without a copy of the status words (a copy that small is a shader copy in the HIP runtime: it cannot
+    // start while the sweep kernels hold every CU, and the chunk's SDMA copy queued behind it waited with it).  May be null.
+    int32_t* skip_host;
 };
+
+// a window the prologue refuses: its status bits, in HBM and (host entry) in the host's skip words
+__device__ __forceinline__ void flag_skipped(const KernelParams& p, int w, int bits)
+{
+    atomicOr(&p.status[w], bits);
+    if (p.skip_host) p.skip_host[w] = bits;
+}
 
 // pairs of pdf values per step in the scratch KernelParams::fscr
 __host__ __device__ constexpr int big_scratch_pairs(int K) { return (K + 1) / 2; }
@@ -855,7 +867,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
 
     if (T <= p.t_lo || T > p.t_hi) __builtin_amdgcn_endpgm();   // another length bucket's window: this block leaves at once
     if (T < 2 || T > NT * L || T > p.ldY) {   // uniform per block
-        if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+        if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_T);
         return;
     }
 
@@ -879,7 +891,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
         x[l] = XPAD;
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
-        if (tid == 0) atomicOr(&p.status[w], HMCG_ST_NONFINITE);
+        if (tid == 0) flag_skipped(p, w, HMCG_ST_NONFINITE);
         return;
     }
     // signal path: positions [sb, se) are "signals" (noisy observations); y[] then holds the current
@@ -896,7 +908,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
             bad_range |= svb < 0 || sve > T || (svb < sve && p.sigvals && sve - svb > p.nsave_ld);
         }
         if (bad_range) {
-            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_RANGE);
+            if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_RANGE);
             return;
         }
         if (sb >= se) { sb = T; se = T; }
@@ -907,7 +919,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     if constexpr (SIG) {
         if (p.end_pos) tail = (T - 1) - p.end_pos[w];
         if (tail < 0 || tail > HMCG_MAXTAIL || tail > T - 1) {      // uniform per block
-            if (tid == 0) atomicOr(&p.status[w], HMCG_ST_BAD_T);
+            if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_T);
             return;
         }
     }

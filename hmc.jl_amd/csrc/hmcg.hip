@@ -919,19 +919,15 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         else c.pool.run(part);
         mark("scattered");
     };
-    int next_scatter = 0;
-    for (int cidx = 0; cidx < nch; ++cidx) {
+    // The copy of chunk c waits on the copy stream for the kernel's event (device-side hand-off); the host blocks on the copy's
+    // event and scatters.  (HMCG_HOST_CHAIN, diagnostics: the host itself watches for the end of kernel c and then issues the
+    // copy, polling the two events in turn -- same timeline, one spinning core; kept because it shows in the trace WHEN each
+    // kernel was seen to end, which is how the late first copy of `profiles/r04/trace_host_entry_skip_words.txt` was found.)
+    const bool device_chain = diag_env("HMCG_HOST_CHAIN") == nullptr;
+    std::vector<char> self_issued((size_t)nch, 0);
+    auto enqueue_kernel = [&](int cidx) -> int {
         const Chunk& ch = chunks[cidx];
         const int slot = cidx % RING;
-        if (stream_draws && cidx >= RING) {
-            // free the ring slot: chunk cidx - RING must have left the device buffer and the pinned buffer
-            while (next_scatter <= cidx - RING) {
-                HIP_TRY(hipEventSynchronize(c.evc[next_scatter % RING]));
-                mark("copy landed");
-                scatter(next_scatter);
-                ++next_scatter;
-            }
-        }
         hmcg::KernelParams p = base;
         p.sweep_begin = ch.s0; p.sweep_end = ch.s1;
         p.resume = (resume_in || cidx > 0) ? 1 : 0;
@@ -940,8 +936,9 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         p.nd_ld = (int32_t)std::max<size_t>(ndc, 1); p.draw_off = (int32_t)ch.d0;
         // The LAST chunk's draws (1/32 of the run, 1.3 MB at the headline shape) are written by the kernel straight into the
         // pinned staging buffer: host memory the device addresses directly, complete at the end of the kernel -- there is no
-        // copy behind the last kernel (it cost ~0.1 ms of the call's tail: nothing left to hide it behind).
-        const bool direct_tail = stream_draws && copy_out && cidx == nch - 1 && !want_corr && nch > 1 &&
+        // copy behind the last kernel (it cost ~0.1 ms of the call's tail: nothing left to hide it behind).  Only the last:
+        // a kernel that writes across the link runs 11 % slower (measured with every chunk direct).
+        const bool direct_tail = stream_draws && copy_out && (cidx == nch - 1 || diag_env("HMCG_DIRECT_ALL")) && !want_corr && nch > 1 &&
                                  diag_env("HMCG_NO_TAIL_COPY") == nullptr && diag_env("HMCG_NO_DIRECT_TAIL") == nullptr;
         if (stream_draws) {
             double* cb = direct_tail ? PP(double, o_pchunk[slot]) : DP(double, o_dchunk[slot]);
@@ -954,27 +951,33 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
             // (a skipped window writes nothing into its block: the scatter zeroes its rows of the caller's arrays instead of
             //  copying them -- no memset node per chunk on the stream)
         }
+        // skips are decided in the first launch's prologue, which notes them in the host's skip words as well (pinned,
+        // zeroed here): the scatter knows which windows' blocks hold nothing once that kernel has ended
+        if (cidx == 0 && stream_draws && copy_out) {
+            memset(P + o_pst0, 0, 4 * N);
+            p.skip_host = PP(int32_t, o_pst0);
+        }
         if (timing) HIP_TRY(hipEventRecord(tev.ev[2 * (size_t)cidx], s));
-        rc = launch_kernel(c, pl, p, s);
-        if (rc) return rc;
+        const int lrc = launch_kernel(c, pl, p, s);
+        if (lrc) return lrc;
         if (timing) HIP_TRY(hipEventRecord(tev.ev[2 * (size_t)cidx + 1], s));
         if (stream_draws) {
-            // the last chunk's copy-out hides behind nothing: it goes on the compute stream itself, right behind its kernel,
-            // instead of paying a cross-stream event hand-off at the tail of the call
+            // the last chunk's copy-out hides behind nothing: it goes on the compute stream itself, right behind its kernel
+            // (or is no copy at all: direct_tail)
             const bool tail_copy = cidx == nch - 1 && !want_corr && diag_env("HMCG_NO_TAIL_COPY") == nullptr;
-            hipStream_t cs = tail_copy ? s : c.copy;
-            if (!tail_copy) {
+            if (tail_copy || direct_tail || device_chain) {
+                hipStream_t cs = tail_copy ? s : c.copy;
+                if (!tail_copy) {
+                    HIP_TRY(hipEventRecord(c.evk[slot], s));
+                    HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
+                }
+                if (ndc > 0 && copy_out && !direct_tail)
+                    HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, cs));
+                HIP_TRY(hipEventRecord(c.evc[slot], cs));
+                self_issued[(size_t)cidx] = 1;
+            } else {
                 HIP_TRY(hipEventRecord(c.evk[slot], s));
-                HIP_TRY(hipStreamWaitEvent(c.copy, c.evk[slot], 0));
             }
-            // skips are decided in the first launch's prologue: its status words travel with the first chunk, so that the
-            // scatter knows which windows' blocks hold nothing
-            if (cidx == 0 && copy_out) HIP_TRY(hipMemcpyAsync(P + o_pst0, D + o_dst, 4 * N, hipMemcpyDeviceToHost, cs));
-            // (one engine's D2H rate, not the PCIe link, bounds a copy: 12 GB/s on the slowest box seen -- there the first
-            //  chunk's 20 MB take 1.7 ms; splitting a chunk over two copy streams changed nothing, measured)
-            if (ndc > 0 && copy_out && !direct_tail)
-                HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, cs));
-            HIP_TRY(hipEventRecord(c.evc[slot], cs));
             if (want_corr && ndc > 0) {
                 // second moments of the chunk's rounded draws, in HBM, beside the chunk's copy-out (calccorr)
                 hmcg_host::MomentsArgs ma{p.mu, p.sig2, p.pi_end, p.A, p.fcast, DP(double, o_dmom), (long long)ndc, (long long)ndc,
@@ -982,29 +985,76 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
                 HIP_TRY(hmcg_host::launch_moments(ma, s));
             }
         }
-    }
-    mark("kernels enqueued");
-    if (want_corr) HIP_TRY(hmcg_host::launch_corr_finalize(DP(double, o_dmom), DP(double, o_dcorr), n, cfg->K, s));
-
-    // ---- small outputs and one-off extras: D2H on the compute stream (after the last kernel) ----
+        return 0;
+    };
+    auto issue_copy = [&](int cidx) -> int {          // kernel cidx is known to be complete: no device-side wait
+        const Chunk& ch = chunks[cidx];
+        const int slot = cidx % RING;
+        const size_t ndc = (size_t)(ch.d1 - ch.d0);
+        // (an SDMA copy: 54 GB/s beside a running sweep kernel.  Nothing small may go ahead of it on this stream: a copy of
+        //  a few KB is a shader copy in the HIP runtime and waits for a free CU, i.e. for the end of the NEXT sweep kernel)
+        if (ndc > 0 && copy_out)
+            HIP_TRY(hipMemcpyAsync(P + o_pchunk[slot], D + o_dchunk[slot], 8 * ncols * N * ndc, hipMemcpyDeviceToHost, c.copy));
+        HIP_TRY(hipEventRecord(c.evc[slot], c.copy));
+        return 0;
+    };
+    auto after_last_kernel = [&]() -> int {
+        mark("kernels enqueued");
+        if (want_corr) HIP_TRY(hmcg_host::launch_corr_finalize(DP(double, o_dmom), DP(double, o_dcorr), n, cfg->K, s));
+        // ---- small outputs and one-off extras: D2H on the compute stream (after the last kernel) ----
 #define D2H(poff, doff, bytes) HIP_TRY(hipMemcpyAsync(P + (poff), D + (doff), (bytes), hipMemcpyDeviceToHost, s))
-    D2H(o_pst, o_dst, (h.summary ? o_dsum + 8 * N * NS : o_dst + 4 * N) - o_dst);        // status | summary, adjacent on both sides
-    if (want_xf) D2H(o_pxf, o_dxf, 4 * N * ld);
-    if (user_pif) D2H(o_ppif, o_dpif, 8 * N * ld * K);
-    if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
-    if (want_fm) D2H(o_pfm, o_dfm, 8 * N * ld * K);
-    if (want_sv) D2H(o_psv, o_dsv, 8 * N * nsv);
-    if (want_ss) D2H(o_pss2, o_dss2, 8 * N * nss);
-    if (want_corr) D2H(o_pcorr, o_dcorr, 8 * N * NCC * NCC);
-    if (ex && ex->xstate) D2H(o_pxs, o_dxs, N * ld);
-    if (ex && ex->sumacc) D2H(o_pacc, o_dacc, 8 * N * (NS + K));
+        D2H(o_pst, o_dst, (h.summary ? o_dsum + 8 * N * NS : o_dst + 4 * N) - o_dst);        // status | summary, adjacent on both sides
+        if (want_xf) D2H(o_pxf, o_dxf, 4 * N * ld);
+        if (user_pif) D2H(o_ppif, o_dpif, 8 * N * ld * K);
+        if (want_sm) D2H(o_psm, o_dsm, 8 * N * ld * K);
+        if (want_fm) D2H(o_pfm, o_dfm, 8 * N * ld * K);
+        if (want_sv) D2H(o_psv, o_dsv, 8 * N * nsv);
+        if (want_ss) D2H(o_pss2, o_dss2, 8 * N * nss);
+        if (want_corr) D2H(o_pcorr, o_dcorr, 8 * N * NCC * NCC);
+        if (ex && ex->xstate) D2H(o_pxs, o_dxs, N * ld);
+        if (ex && ex->sumacc) D2H(o_pacc, o_dacc, 8 * N * (NS + K));
 #undef D2H
-    // drain the chunk pipeline while those copies run
-    if (stream_draws) {
-        for (; next_scatter < nch; ++next_scatter) {
-            HIP_TRY(hipEventSynchronize(c.evc[next_scatter % RING]));
-            mark("copy landed");
-            scatter(next_scatter);
+        return 0;
+    };
+    auto done = [&](hipEvent_t e, bool& yes) -> int {
+        const hipError_t q = hipEventQuery(e);
+        if (q == hipSuccess) { yes = true; return 0; }
+        yes = false;
+        if (q == hipErrorNotReady) return 0;
+        set_err("hipEventQuery failed: %s (%s:%d)", hipGetErrorString(q), __FILE__, __LINE__);
+        return (int)q;
+    };
+    {
+        int enq = 0, iss = 0, sca = 0;
+        while (enq < nch || (stream_draws && sca < nch)) {
+            bool progress = false;
+            while (enq < nch && (!stream_draws || enq < sca + RING)) {
+                rc = enqueue_kernel(enq);
+                if (rc) return rc;
+                if (++enq == nch) { rc = after_last_kernel(); if (rc) return rc; }
+                progress = true;
+            }
+            if (!stream_draws) break;
+            if (iss < enq) {
+                bool yes = self_issued[(size_t)iss] != 0;
+                if (!yes) {
+                    rc = done(c.evk[iss % RING], yes);
+                    if (rc) return rc;
+                    if (yes) { mark("kernel seen"); rc = issue_copy(iss); if (rc) return rc; }
+                }
+                if (yes) { ++iss; progress = true; }
+            }
+            if (sca < iss) {
+                bool yes = false;
+                rc = done(c.evc[sca % RING], yes);
+                if (rc) return rc;
+                if (yes) { mark("copy landed"); scatter(sca); ++sca; progress = true; }
+            }
+            if (!progress) {
+                // nothing but the oldest outstanding copy to wait for: block on it; otherwise (host chain) keep polling
+                if (sca < iss && iss == enq) HIP_TRY(hipEventSynchronize(c.evc[sca % RING]));
+                else __builtin_ia32_pause();
+            }
         }
     }
     mark("chunks scattered");
@@ -1032,6 +1082,15 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     if (trace_on) {
         fprintf(stderr, "[trace] device %d, %d windows, %d chunks:", c.device, n, nch);
         for (const auto& t : trace) fprintf(stderr, " %s %.3f |", t.first, t.second);
+        if (timing) {
+            fprintf(stderr, " chunk kernels (ms @ start after the first one's start):");
+            for (int cidx = 0; cidx < nch; ++cidx) {
+                float ms = 0.f, at = 0.f;
+                (void)hipEventElapsedTime(&ms, tev.ev[2 * (size_t)cidx], tev.ev[2 * (size_t)cidx + 1]);
+                (void)hipEventElapsedTime(&at, tev.ev[0], tev.ev[2 * (size_t)cidx]);
+                fprintf(stderr, " %.3f@%.3f", ms, at);
+            }
+        }
         fprintf(stderr, "\n");
     }
     if (timing) {
