@@ -48,7 +48,7 @@ struct BigShared {
     uint32_t wmap[NW][2];         // per-wave composed state map, byte-per-entry in two words
     double ulast;
     double bred[NW];
-    double med[2];
+    int selcnt[2][2][8];          // block_select2 (init)
     double fcM[2][K * K];         // forecast scratch (cooperative matrix power on the forecast wave)
     double fcv[2][K];
     double fcval[HMCG_MAXH];
@@ -238,26 +238,17 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         for (int t = tid; t < T; t += NT) { lmin = fmin(lmin, ylds[t]); lmax = fmax(lmax, ylds[t]); }
         const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
         const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
-        for (int i0 = 0; i0 < L; i0 += 4) {                       // median by rank counting, 4 own elements per pass
-            double yo[4];
-            int to[4], rank[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { to[i] = tid + (i0 + i) * NT; yo[i] = (i0 + i < L) ? ylds[to[i] < cap ? to[i] : 0] : 0.0; rank[i] = 0; }
-            for (int j = 0; j < T; ++j) {
-                const double yj = ylds[j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rank[i] += (yj < yo[i] || (yj == yo[i] && j < to[i])) ? 1 : 0;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i0 + i < L && to[i] < T && rank[i] == (T - 1) / 2) sh.med[0] = yo[i];
-                if (i0 + i < L && to[i] < T && rank[i] == T / 2) sh.med[1] = yo[i];
-            }
-        }
-        __syncthreads();
+        // median: the two middle order statistics by radix selection over the LDS-resident window (gibbs_device.hpp)
+        unsigned long long mk0, mk1;
+        block_select2<NW, 0>(L, [&](int i, unsigned long long& k) __attribute__((always_inline)) {
+                              const int t = tid + i * NT;
+                              k = order_key(ylds[t < T ? t : 0]);
+                              return t < T;
+                          }, (T - 1) / 2, T / 2, sh.selcnt, wave, lane, mk0, mk1);
+        const double med_lo = key_value(mk0), med_hi = key_value(mk1);
         {
 #pragma clang fp contract(off)
-            const double med = (T & 1) ? sh.med[0] : sh.med[0] / 2 + sh.med[1] / 2;
+            const double med = (T & 1) ? med_lo : med_lo / 2 + med_hi / 2;
             const double R = ymax - ymin;
             const double lo = med - 0.25 * R, hi = med + 0.25 * R;
             double mu0[K];

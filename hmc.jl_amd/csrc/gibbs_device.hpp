@@ -749,7 +749,7 @@ struct SweepShared {
     double ulast;                 // the uniform that draws X[T-1]
     int xfirst[NT + 1];           // init only: first state of each thread's chunk
     double bred[NW];              // generic block reductions (init)
-    double med[2];
+    int selcnt[2][2][8];          // block_select2 (init): by round parity, rank, wave
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
     double exptab[EXPTAB_N * EXPTAB_C];   // 2^(j/N), j = 0..N-1, EXPTAB_C copies (entry j of copy c at [j * EXPTAB_C + c])
     // decoded output role of every lane of the (at most two) output waves, staged once per launch: slot 0 = the
@@ -786,6 +786,62 @@ __device__ __forceinline__ double block_minmax(double v, double* bred, int wave,
 #pragma unroll
     for (int w = 1; w < NW; ++w) t = is_max ? fmax(t, bred[w]) : fmin(t, bred[w]);
     return t;
+}
+
+// ---- the window's median without a sort: binary radix selection on order-preserving integer keys ----
+// order_key: unsigned integers whose order is the doubles' order (finite values; -0.0 is folded into +0.0 first, so that
+// equal doubles have equal keys); key_value is its inverse.
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const long long b = __double_as_longlong(v + 0.0);
+    return (unsigned long long)(b ^ ((b >> 63) | (long long)0x8000000000000000ull));
+}
+__device__ __forceinline__ double key_value(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k ^ 0x8000000000000000ull) : ~k));
+}
+// The values of ranks r0 <= r1 (0-based, r1 - r0 <= 1) among the block's live elements: 64 rounds, one key bit each, most
+// significant first.  A round counts the elements that agree with the bits chosen so far and have a 0 in this bit (ballot and
+// popcount per wave, one LDS word per wave and rank, one barrier): rank below the count -> the bit is 0, else it is 1 and the
+// count leaves the rank.  `elem(i, key)` hands out the thread's i-th key and whether it is live, i < n (n uniform).  Every
+// wave of the block must call it (barriers); waves >= NW have no live elements.  cnt: LDS, [2][2][8] ints.
+// (Round 4: replaces counting every element's rank against every other -- T^2 / NT compares per thread, 0.18 ms of a
+//  fresh launch at T = 1000 and 1.1 ms at T = 5000; the selection takes ~15 us.  The median VALUE is the same: exact.)
+template <int NW, int NE, typename ElemFn>          // NE > 0: that many elements per thread (unrolled); 0: n of them
+__device__ __forceinline__ void block_select2(int n, ElemFn elem, int r0, int r1, int (*cnt)[2][8], int wave, int lane,
+                                              unsigned long long& k0, unsigned long long& k1)
+{
+    unsigned long long prefix[2] = {0ull, 0ull}, mask = 0ull;
+    int r[2] = {r0, r1};
+    const bool two = r1 != r0;                       // uniform: an odd T asks for one rank only
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long bit = 1ull << b;
+        int c0 = 0, c1 = 0;
+        auto one = [&](int i) __attribute__((always_inline)) {
+            unsigned long long key;
+            const bool live = elem(i, key);
+            const bool zero = live && !(key & bit);
+            c0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(zero && ((key ^ prefix[0]) & mask) == 0ull));
+            if (two) c1 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(zero && ((key ^ prefix[1]) & mask) == 0ull));
+        };
+        if constexpr (NE > 0) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) one(i);
+        } else {
+            for (int i = 0; i < n; ++i) one(i);
+        }
+        if (lane == 0 && wave < NW) { cnt[b & 1][0][wave] = c0; cnt[b & 1][1][wave] = c1; }
+        __syncthreads();
+        int t0 = 0, t1 = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t0 += cnt[b & 1][0][w]; t1 += cnt[b & 1][1][w]; }
+        t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
+        if (r[0] >= t0) { r[0] -= t0; prefix[0] |= bit; }
+        if (two && r[1] >= t1) { r[1] -= t1; prefix[1] |= bit; }
+        mask |= bit;
+    }
+    k0 = prefix[0];
+    k1 = two ? prefix[1] : prefix[0];
 }
 
 // sortperm(mu) (src/Hmc.jl:501): stable rank of each entry
@@ -957,30 +1013,17 @@ void gibbs_sweeps_kernel(const KernelParams p)
         for (int l = 0; l < L; ++l) if (t0 + l < T) { lmin = fmin(lmin, y[l]); lmax = fmax(lmax, y[l]); }
         const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
         const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
-        // median by rank counting over the LDS-staged window
-        if (!helper) {
+        // median: the two middle order statistics by radix selection (block_select2)
+        unsigned long long key[L], mk0, mk1;
 #pragma unroll
-            for (int l = 0; l < L; ++l) sh.ux[t0 + l] = y[l];
-        }
-        __syncthreads();
-        int rank[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l) rank[l] = 0;
-        for (int j = 0; j < (helper ? 0 : T); ++j) {
-            const double yj = sh.ux[j];
-#pragma unroll
-            for (int l = 0; l < L; ++l) rank[l] += (yj < y[l] || (yj == y[l] && j < t0 + l)) ? 1 : 0;
-        }
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            if (t0 + l < T && rank[l] == (T - 1) / 2) sh.med[0] = y[l];
-            if (t0 + l < T && rank[l] == T / 2) sh.med[1] = y[l];
-        }
-        __syncthreads();
+        for (int l = 0; l < L; ++l) key[l] = order_key(y[l]);
+        block_select2<NW, L>(L, [&](int l, unsigned long long& k) __attribute__((always_inline)) { k = key[l]; return !helper && t0 + l < T; },
+                          (T - 1) / 2, T / 2, sh.selcnt, wave, lane, mk0, mk1);
+        const double med_lo = key_value(mk0), med_hi = key_value(mk1);
         {
             // bit-identical to the oracle: no FMA contraction in this block (tie rule, see above)
 #pragma clang fp contract(off)
-            const double med = (T & 1) ? sh.med[0] : sh.med[0] / 2 + sh.med[1] / 2;
+            const double med = (T & 1) ? med_lo : med_lo / 2 + med_hi / 2;
             const double R = ymax - ymin;
             const double lo = med - 0.25 * R, hi = med + 0.25 * R;
             double mu0[K];
