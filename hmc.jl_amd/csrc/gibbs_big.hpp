@@ -48,7 +48,7 @@ struct BigShared {
     uint32_t wmap[NW][2];         // per-wave composed state map, byte-per-entry in two words
     double ulast;
     double bred[NW];
-    int selcnt[2][2][8];          // block_select2 (init)
+    int selcnt[2][8];             // block_select (init)
     double fcM[2][K * K];         // forecast scratch (cooperative matrix power on the forecast wave)
     double fcv[2][K];
     double fcval[HMCG_MAXH];
@@ -238,14 +238,25 @@ __global__ __launch_bounds__(NT) void gibbs_sweeps_kernel_big(const KernelParams
         for (int t = tid; t < T; t += NT) { lmin = fmin(lmin, ylds[t]); lmax = fmax(lmax, ylds[t]); }
         const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
         const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
-        // median: the two middle order statistics by radix selection over the LDS-resident window (gibbs_device.hpp)
-        unsigned long long mk0, mk1;
-        block_select2<NW, 0>(L, [&](int i, unsigned long long& k) __attribute__((always_inline)) {
-                              const int t = tid + i * NT;
-                              k = order_key(ylds[t < T ? t : 0]);
-                              return t < T;
-                          }, (T - 1) / 2, T / 2, sh.selcnt, wave, lane, mk0, mk1);
-        const double med_lo = key_value(mk0), med_hi = key_value(mk1);
+        // median: the lower middle order statistic by radix selection over the LDS-resident window (gibbs_device.hpp,
+        // block_select); for an even T the upper one from one more count and a minimum
+        const int rlo = (T - 1) / 2;
+        const double med_lo = key_value(block_select<NW, 0>(L, [&](int i, unsigned long long& k) __attribute__((always_inline)) {
+                                                                const int t = tid + i * NT;
+                                                                k = order_key(ylds[t < T ? t : 0]);
+                                                                return t < T;
+                                                            }, rlo, sh.selcnt, wave, lane));
+        double med_hi = med_lo;
+        if (!(T & 1)) {                  // uniform
+            double nle = 0.0, above = 1.0e308;
+            for (int t = tid; t < T; t += NT) {
+                if (ylds[t] <= med_lo) nle += 1.0;
+                else above = fmin(above, ylds[t]);
+            }
+            const double cle = block_sum<NW>(nle, sh.bred, wave, lane);
+            const double nxt = block_minmax<NW>(above, sh.bred, wave, lane, false);
+            med_hi = (cle > (double)(rlo + 1)) ? med_lo : nxt;
+        }
         {
 #pragma clang fp contract(off)
             const double med = (T & 1) ? med_lo : med_lo / 2 + med_hi / 2;

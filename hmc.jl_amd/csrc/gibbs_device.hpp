@@ -749,7 +749,7 @@ struct SweepShared {
     double ulast;                 // the uniform that draws X[T-1]
     int xfirst[NT + 1];           // init only: first state of each thread's chunk
     double bred[NW];              // generic block reductions (init)
-    int selcnt[2][2][8];          // block_select2 (init): by round parity, rank, wave
+    int selcnt[2][8];             // block_select (init): by round parity, wave
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
     double exptab[EXPTAB_N * EXPTAB_C];   // 2^(j/N), j = 0..N-1, EXPTAB_C copies (entry j of copy c at [j * EXPTAB_C + c])
     // decoded output role of every lane of the (at most two) output waves, staged once per launch: slot 0 = the
@@ -800,48 +800,44 @@ __device__ __forceinline__ double key_value(unsigned long long k)
 {
     return __longlong_as_double((long long)((k >> 63) ? (k ^ 0x8000000000000000ull) : ~k));
 }
-// The values of ranks r0 <= r1 (0-based, r1 - r0 <= 1) among the block's live elements: 64 rounds, one key bit each, most
-// significant first.  A round counts the elements that agree with the bits chosen so far and have a 0 in this bit (ballot and
-// popcount per wave, one LDS word per wave and rank, one barrier): rank below the count -> the bit is 0, else it is 1 and the
-// count leaves the rank.  `elem(i, key)` hands out the thread's i-th key and whether it is live, i < n (n uniform).  Every
-// wave of the block must call it (barriers); waves >= NW have no live elements.  cnt: LDS, [2][2][8] ints.
+// The key of rank r (0-based) among the block's live elements: 64 rounds, one key bit each, most significant first.  A
+// round counts the elements that agree with the bits chosen so far and have a 0 in this bit (ballot and popcount per wave,
+// one LDS word per wave, one barrier): rank below the count -> the bit is 0, else it is 1 and the count leaves the rank.
+// `elem(i, key)` hands out the thread's i-th key and whether it is live.  Every wave of the block must call it (barriers);
+// waves >= NW have no elements and only keep the barriers.  cnt: LDS, [2][8] ints (by round parity, wave).
 // (Round 4: replaces counting every element's rank against every other -- T^2 / NT compares per thread, 0.18 ms of a
-//  fresh launch at T = 1000 and 1.1 ms at T = 5000; the selection takes ~15 us.  The median VALUE is the same: exact.)
+//  fresh launch at T = 1000 and 13 ms at T = 5000.  The median VALUE is the same: exact.)
 template <int NW, int NE, typename ElemFn>          // NE > 0: that many elements per thread (unrolled); 0: n of them
-__device__ __forceinline__ void block_select2(int n, ElemFn elem, int r0, int r1, int (*cnt)[2][8], int wave, int lane,
-                                              unsigned long long& k0, unsigned long long& k1)
+__device__ __forceinline__ unsigned long long block_select(int n, ElemFn elem, int r, int (*cnt)[8], int wave, int lane)
 {
-    unsigned long long prefix[2] = {0ull, 0ull}, mask = 0ull;
-    int r[2] = {r0, r1};
-    const bool two = r1 != r0;                       // uniform: an odd T asks for one rank only
+    unsigned long long prefix = 0ull, mask = 0ull;
+    const bool mine = __builtin_amdgcn_readfirstlane(wave) < NW;
     for (int b = 63; b >= 0; --b) {
         const unsigned long long bit = 1ull << b;
-        int c0 = 0, c1 = 0;
-        auto one = [&](int i) __attribute__((always_inline)) {
-            unsigned long long key;
-            const bool live = elem(i, key);
-            const bool zero = live && !(key & bit);
-            c0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(zero && ((key ^ prefix[0]) & mask) == 0ull));
-            if (two) c1 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(zero && ((key ^ prefix[1]) & mask) == 0ull));
-        };
-        if constexpr (NE > 0) {
+        if (mine) {
+            int c = 0;
+            auto one = [&](int i) __attribute__((always_inline)) {
+                unsigned long long key;
+                const bool live = elem(i, key);
+                c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !(key & bit) && ((key ^ prefix) & mask) == 0ull));
+            };
+            if constexpr (NE > 0) {
 #pragma unroll
-            for (int i = 0; i < NE; ++i) one(i);
-        } else {
-            for (int i = 0; i < n; ++i) one(i);
+                for (int i = 0; i < NE; ++i) one(i);
+            } else {
+                for (int i = 0; i < n; ++i) one(i);
+            }
+            if (lane == 0) cnt[b & 1][wave] = c;
         }
-        if (lane == 0 && wave < NW) { cnt[b & 1][0][wave] = c0; cnt[b & 1][1][wave] = c1; }
         __syncthreads();
-        int t0 = 0, t1 = 0;
+        int t = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { t0 += cnt[b & 1][0][w]; t1 += cnt[b & 1][1][w]; }
-        t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
-        if (r[0] >= t0) { r[0] -= t0; prefix[0] |= bit; }
-        if (two && r[1] >= t1) { r[1] -= t1; prefix[1] |= bit; }
+        for (int w = 0; w < NW; ++w) t += cnt[b & 1][w];
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (r >= t) { r -= t; prefix |= bit; }
         mask |= bit;
     }
-    k0 = prefix[0];
-    k1 = two ? prefix[1] : prefix[0];
+    return prefix;
 }
 
 // sortperm(mu) (src/Hmc.jl:501): stable rank of each entry
@@ -1013,13 +1009,28 @@ void gibbs_sweeps_kernel(const KernelParams p)
         for (int l = 0; l < L; ++l) if (t0 + l < T) { lmin = fmin(lmin, y[l]); lmax = fmax(lmax, y[l]); }
         const double ymin = block_minmax<NW>(lmin, sh.bred, wave, lane, false);
         const double ymax = block_minmax<NW>(lmax, sh.bred, wave, lane, true);
-        // median: the two middle order statistics by radix selection (block_select2)
-        unsigned long long key[L], mk0, mk1;
+        // median: the lower middle order statistic by radix selection (block_select); for an even T the upper one is the same
+        // value when more than (T-1)/2 + 1 elements are <= it, else the smallest value above it
+        unsigned long long key[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) key[l] = order_key(y[l]);
-        block_select2<NW, L>(L, [&](int l, unsigned long long& k) __attribute__((always_inline)) { k = key[l]; return !helper && t0 + l < T; },
-                          (T - 1) / 2, T / 2, sh.selcnt, wave, lane, mk0, mk1);
-        const double med_lo = key_value(mk0), med_hi = key_value(mk1);
+        const int rlo = (T - 1) / 2;
+        const double med_lo = key_value(block_select<NW, L>(L, [&](int l, unsigned long long& k) __attribute__((always_inline)) { k = key[l]; return t0 + l < T; },
+                                                            rlo, sh.selcnt, wave, lane));
+        double med_hi = med_lo;
+        if (!(T & 1)) {                  // uniform
+            double nle = 0.0, above = 1.0e308;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                if (!helper && t0 + l < T) {
+                    if (y[l] <= med_lo) nle += 1.0;
+                    else above = fmin(above, y[l]);
+                }
+            }
+            const double cle = block_sum<NW>(nle, sh.bred, wave, lane);
+            const double nxt = block_minmax<NW>(above, sh.bred, wave, lane, false);
+            med_hi = (cle > (double)(rlo + 1)) ? med_lo : nxt;
+        }
         {
             // bit-identical to the oracle: no FMA contraction in this block (tie rule, see above)
 #pragma clang fp contract(off)
