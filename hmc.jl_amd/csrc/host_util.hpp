@@ -109,8 +109,10 @@ inline std::vector<Chunk> plan_chunks(int sb, int se, int per, int burnin, int n
     long long fdiv = 32;       // (measured at the headline shape: 1/8 5.34 ms, 1/16 5.30, 1/32 5.23 per call)
     if (const char* e = fdiv_env) { const long long v = atoll(e); if (v >= 2 && v <= 1024) fdiv = v; }
     const long long floor_sz = std::max(16LL, nd / fdiv);
-    // share of the remaining draws a chunk takes (default 1/2)
-    long long keep_num = 1, keep_den = 2;
+    // share of the remaining draws a chunk takes: 2/3 (four launches at the headline shape: 667, 222, 74, 37 draws).  Until
+    // the chunk copies set out on time (round 4, KernelParams::skip_host) 1/2 measured better -- its smaller first chunk hid
+    // the late first copy; now every relaunch saved is ~30 us (profiles/r04/trace_host_entry_skip_words.txt)
+    long long keep_num = 2, keep_den = 3;
     if (const char* e = keep_env) {
         long long a = 0, b = 0;
         if (sscanf(e, "%lld/%lld", &a, &b) == 2 && a >= 1 && b > a && b <= 64) { keep_num = a; keep_den = b; }
