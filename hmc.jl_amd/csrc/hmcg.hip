@@ -801,8 +801,12 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
 #define PP(T_, off) reinterpret_cast<T_*>(P + (off))
 
     // ---- pack the inputs (rows idx[i] of the caller's arrays) into pinned staging, one H2D each ----
+    // (Y is the bulk, 2 MB at the headline shape: its first half sets out while the second half is packed)
+#define H2D(doff, poff, bytes) HIP_TRY(hipMemcpyAsync(D + (doff), P + (poff), (bytes), hipMemcpyHostToDevice, s))
+    const int n_early = ((size_t)8 * ld * n >= ((size_t)1 << 20) && o_pY == 0 && o_dY == 0 && !diag_env("HMCG_NO_EARLY_H2D")) ? n / 2 : 0;
     for (int i = 0; i < n; ++i) {
         const size_t g = row(i);
+        if (i == n_early && n_early > 0) H2D(0, 0, (size_t)8 * ld * n_early);
         memcpy(PP(double, o_pY) + (size_t)i * ld, h.Y + g * ld, 8 * ld);
         PP(int32_t, o_pT)[i] = h.T[g];
         PP(uint32_t, o_pwid)[i] = (ex && ex->window_ids) ? ex->window_ids[g] : cfg->window_base + (uint32_t)g;
@@ -823,8 +827,10 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
         }
     }
     mark("packed");
-#define H2D(doff, poff, bytes) HIP_TRY(hipMemcpyAsync(D + (doff), P + (poff), (bytes), hipMemcpyHostToDevice, s))
-    H2D(0, 0, input_bytes);                                    // Y, T, ids, yreal and the optional per-window inputs
+    {
+        const size_t sent = (size_t)8 * ld * n_early;          // Y, T, ids, yreal and the optional per-window inputs
+        H2D(sent, sent, input_bytes - sent);
+    }
     if (resume_in) {
         H2D(o_dst, o_pst, 4 * N);
         H2D(o_dxs, o_pxs, N * ld);
