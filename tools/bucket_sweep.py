@@ -24,7 +24,6 @@ def timed(label, bucketed=True):
 
 timed("one launch", bucketed=False)
 timed("table")
-os.environ["HMCG_BUCKET_PRIO"] = "0,0,0"
-for combo in ("p2,p2,p2", "p1,p1,p1", "h,p3,p3", "h,p2,p3", "h,p3,p2", "p2,p3,p3", "p1,p2,p3", "p1,p3,p3"):
+for combo in ("p2,p2,p2", "p1,p1,p1", "p1,p1,p2", "p1,p2,p2", "p2,p1,p1", "p2,p2,p1", "h,p1,p1", "p1,p2,p1"):
     os.environ["HMCG_BUCKET_FLAVOURS"] = combo
     timed(combo)
