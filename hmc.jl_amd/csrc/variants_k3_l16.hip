@@ -5,6 +5,6 @@
 #include <hip/hip_runtime.h>
 #include "variants.hpp"
 namespace hmcg_host {
-static const Variant k3l16[] = { HMCG_V3(3, 16, false, false, P1, P2) };
+static const Variant k3l16[] = { HMCG_V3(3, 16, false, false, H, P2) };
 HMCG_GROUP(g_group_k3_l16, k3l16);
 }

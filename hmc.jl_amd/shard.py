@@ -69,8 +69,11 @@ def gather_blocks(local_block, local_ids, W_total, group=None, dst=0, force_coll
     dist.gather(pad, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    out = torch.zeros((W_total, C), dtype=local_block.dtype, device=local_block.device)
-    for b in bufs:
-        keep = b[:, C] >= 0
-        out[b[keep, C].to(torch.int64)] = b[keep, :C]
-    return out
+    # place every row at its global id in one indexed store; padding rows (id -1) go to a spare row that is cut off again --
+    # no boolean-mask indexing, which would make the host wait for the device once per rank
+    allb = torch.cat(bufs, dim=0)
+    idx = allb[:, C].to(torch.int64)
+    idx = torch.where(idx >= 0, idx, torch.full_like(idx, W_total))
+    out = torch.zeros((W_total + 1, C), dtype=local_block.dtype, device=local_block.device)
+    out[idx] = allb[:, :C]
+    return out[:W_total]
