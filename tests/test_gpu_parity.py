@@ -608,3 +608,28 @@ def test_per_draw_smoothed_probabilities(hmclib, oracle, monkeypatch, K, lens):
     monkeypatch.setenv("HMCG_CHUNK_DRAWS", "3")
     c = _lib.estimate_batch_host(*args, want_state=True, want_smooth_draws=True)
     assert c["launches"] >= 3 and np.array_equal(c["pi_smooth_draws"], g["pi_smooth_draws"]) and np.array_equal(c["mu"], g["mu"])
+
+
+@pytest.mark.parametrize("K,lens", [(3, [1000, 999, 64, 7, 2, 513, 2050]), (2, [300, 301]), (4, [700, 1001]), (8, [900, 901, 5000]), (5, [64, 65])])
+def test_median_selection_with_ties_and_signed_zeros(hmclib, oracle, K, lens):
+    """The fresh start's median (makeParams, src/Hmc.jl:161-195) is a radix selection over integer keys (block_select,
+    csrc/gibbs_device.hpp); the oracle sorts.  Data made of few distinct values -- quantised to one decimal, with runs of
+    equal middle elements, exact zeros of both signs, even and odd T, windows of one value repeated but for two entries --
+    must give the same initial state path and hence the same chain (state paths bit-exact) on both kernels."""
+    rng = np.random.default_rng(42)
+    W, ld = len(lens), max(lens)
+    Y = np.zeros((W, ld))
+    for w, T in enumerate(lens):
+        y = np.round(rng.normal(0.0, 1.0, T) + (rng.random(T) < 0.3) * 2.0, 1)
+        y[rng.random(T) < 0.15] = 0.0
+        y[rng.random(T) < 0.10] = -0.0
+        if w % 3 == 2 and T > 4:                       # nearly constant: the two middle elements are the same value
+            y[:] = 0.5
+            y[0], y[-1] = -1.0, 2.0
+        Y[w, :T] = y
+    Tw = np.array(lens, dtype=np.int32)
+    yreal = rng.normal(0.0, 1.0, (W, 1))
+    for lo in range(0, W, 3):                           # (the oracle is sequential: a few windows at a time)
+        idx = np.arange(lo, min(lo + 3, W))
+        l2 = int(Tw[idx].max())
+        check_against_oracle(oracle, np.ascontiguousarray(Y[idx, :l2]), Tw[idx], K, 2, 6 if l2 > 2000 else 12, (12,), yreal[idx])

@@ -1,3 +1,7 @@
+"""Per-launch fixed cost of the sweep kernel at the headline shape (K=3, T=1000, 256 windows): kernel time of runs of 1..1000
+sweeps through the device entry, and of 1- and 31-sweep runs through the host entry in one launch with and without
+caller-provided initial states (x_init skips makeParams' median / nearest-mean start).  profiles/r04/fixed_cost.txt.
+usage: python tools/fixed_cost.py"""
 import os, sys
 os.environ.setdefault("HMCG_DIAG", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
