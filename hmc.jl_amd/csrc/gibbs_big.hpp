@@ -48,7 +48,7 @@ struct BigShared {
     uint32_t wmap[NW][2];         // per-wave composed state map, byte-per-entry in two words
     double ulast;
     double bred[NW];
-    int selcnt[2][8];             // block_select (init)
+    int selcnt[2][8][3];          // block_select (init)
     double fcM[2][K * K];         // forecast scratch (cooperative matrix power on the forecast wave)
     double fcv[2][K];
     double fcval[HMCG_MAXH];

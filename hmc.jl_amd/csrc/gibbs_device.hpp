@@ -749,7 +749,7 @@ struct SweepShared {
     double ulast;                 // the uniform that draws X[T-1]
     int xfirst[NT + 1];           // init only: first state of each thread's chunk
     double bred[NW];              // generic block reductions (init)
-    int selcnt[2][8];             // block_select (init): by round parity, wave
+    int selcnt[2][8][3];          // block_select (init): by round parity, wave, digit
     double ux[NT * L];            // this sweep's uniforms for the state draws (init: Y staged for the median)
     double exptab[EXPTAB_N * EXPTAB_C];   // 2^(j/N), j = 0..N-1, EXPTAB_C copies (entry j of copy c at [j * EXPTAB_C + c])
     // decoded output role of every lane of the (at most two) output waves, staged once per launch: slot 0 = the
@@ -800,26 +800,31 @@ __device__ __forceinline__ double key_value(unsigned long long k)
 {
     return __longlong_as_double((long long)((k >> 63) ? (k ^ 0x8000000000000000ull) : ~k));
 }
-// The key of rank r (0-based) among the block's live elements: 64 rounds, one key bit each, most significant first.  A
-// round counts the elements that agree with the bits chosen so far and have a 0 in this bit (ballot and popcount per wave,
-// one LDS word per wave, one barrier): rank below the count -> the bit is 0, else it is 1 and the count leaves the rank.
-// `elem(i, key)` hands out the thread's i-th key and whether it is live.  Every wave of the block must call it (barriers);
-// waves >= NW have no elements and only keep the barriers.  cnt: LDS, [2][8] ints (by round parity, wave).
+// The key of rank r (0-based) among the block's live elements: 32 rounds, two key bits each, most significant first.  A
+// round counts, among the elements that agree with the bits chosen so far, those whose next two bits are 00, 01, 10 (ballot
+// and popcount per wave, three LDS words per wave, one barrier); the rank falls into one of the four digit classes, whose
+// digit is appended and whose predecessors' counts leave the rank.  `elem(i, key)` hands out the thread's i-th key and
+// whether it is live.  Every wave of the block must call it (barriers); waves >= NW have no elements and only keep the
+// barriers.  cnt: LDS, [2][8][3] ints (by round parity, wave, digit).
 // (Round 4: replaces counting every element's rank against every other -- T^2 / NT compares per thread, 0.18 ms of a
 //  fresh launch at T = 1000 and 13 ms at T = 5000.  The median VALUE is the same: exact.)
 template <int NW, int NE, typename ElemFn>          // NE > 0: that many elements per thread (unrolled); 0: n of them
-__device__ __forceinline__ unsigned long long block_select(int n, ElemFn elem, int r, int (*cnt)[8], int wave, int lane)
+__device__ __forceinline__ unsigned long long block_select(int n, ElemFn elem, int r, int (*cnt)[8][3], int wave, int lane)
 {
     unsigned long long prefix = 0ull, mask = 0ull;
     const bool mine = __builtin_amdgcn_readfirstlane(wave) < NW;
-    for (int b = 63; b >= 0; --b) {
-        const unsigned long long bit = 1ull << b;
+    for (int b = 62; b >= 0; b -= 2) {
+        const int par = (b >> 1) & 1;
         if (mine) {
-            int c = 0;
+            int c0 = 0, c1 = 0, c2 = 0;
             auto one = [&](int i) __attribute__((always_inline)) {
                 unsigned long long key;
                 const bool live = elem(i, key);
-                c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !(key & bit) && ((key ^ prefix) & mask) == 0ull));
+                const bool cand = live && ((key ^ prefix) & mask) == 0ull;
+                const unsigned digit = (unsigned)(key >> b) & 3u;
+                c0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand && digit == 0u));
+                c1 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand && digit == 1u));
+                c2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand && digit == 2u));
             };
             if constexpr (NE > 0) {
 #pragma unroll
@@ -827,15 +832,19 @@ __device__ __forceinline__ unsigned long long block_select(int n, ElemFn elem, i
             } else {
                 for (int i = 0; i < n; ++i) one(i);
             }
-            if (lane == 0) cnt[b & 1][wave] = c;
+            if (lane == 0) { cnt[par][wave][0] = c0; cnt[par][wave][1] = c1; cnt[par][wave][2] = c2; }
         }
         __syncthreads();
-        int t = 0;
+        int t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) t += cnt[b & 1][w];
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (r >= t) { r -= t; prefix |= bit; }
-        mask |= bit;
+        for (int w = 0; w < NW; ++w) { t0 += cnt[par][w][0]; t1 += cnt[par][w][1]; t2 += cnt[par][w][2]; }
+        t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1); t2 = __builtin_amdgcn_readfirstlane(t2);
+        unsigned long long digit = 0ull;
+        if (r >= t0) { r -= t0; digit = 1ull;
+            if (r >= t1) { r -= t1; digit = 2ull;
+                if (r >= t2) { r -= t2; digit = 3ull; } } }
+        prefix |= digit << b;
+        mask |= 3ull << b;
     }
     return prefix;
 }
