@@ -6,7 +6,7 @@
 #include "variants.hpp"
 namespace hmcg_host {
 static const Variant mid[] = {
-    HMCG_V3(3, 3, false, false, H, P1), HMCG_V3(3, 6, false, false, H, P2), HMCG_V3(3, 12, false, false, H, P2),
+    HMCG_V3(3, 3, false, false, H, P2), HMCG_V3(3, 6, false, false, H, P2), HMCG_V3(3, 12, false, false, H, P2),
     HMCG_V3(2, 3, false, false, H, P1), HMCG_V3(4, 3, false, false, H, P2),
     HMCG_V3(3, 3, true, false, H, P2),
 };
