@@ -7,7 +7,7 @@ TAG=${1:-r01}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-extra > "$O/trace.log" 2>&1; echo trace=$?
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 "$R/bench.py" --no-cpu-baseline --no-extra > "$O/trace.log" 2>&1; echo trace=$?
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$O/pmc_fetch.log" 2>&1; echo fetch=$?
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$O/pmc_write.log" 2>&1; echo write=$?
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d "$O/pmc_sq" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$O/pmc_sq.log" 2>&1; echo sq=$?
