@@ -806,7 +806,7 @@ int run_host_on_device(DeviceCtx& c, const hmcg_config* cfg, const int32_t* idx,
     const int n_early = ((size_t)8 * ld * n >= ((size_t)1 << 20) && o_pY == 0 && o_dY == 0 && !diag_env("HMCG_NO_EARLY_H2D")) ? n / 2 : 0;
     for (int i = 0; i < n; ++i) {
         const size_t g = row(i);
-        if (i == n_early && n_early > 0) H2D(0, 0, (size_t)8 * ld * n_early);
+        if (i == n_early && n_early > 0) { mark("half packed"); H2D(0, 0, (size_t)8 * ld * n_early); mark("first half sent"); }
         memcpy(PP(double, o_pY) + (size_t)i * ld, h.Y + g * ld, 8 * ld);
         PP(int32_t, o_pT)[i] = h.T[g];
         PP(uint32_t, o_pwid)[i] = (ex && ex->window_ids) ? ex->window_ids[g] : cfg->window_base + (uint32_t)g;
