@@ -323,8 +323,8 @@ def main():
     st = None
     if world == 1:
         st = torch.cuda.Stream(device=local_rank)      # (a stream of its own: the library takes stream 0 to mean "use your own")
-        if args.warmup > 0:                            # first use of a stream is not free: inside the warm-up, not the timed region
-            panel.run(burnin=0, seed=1234, window_base=ids[0], threads_per_window=args.threads_per_window, timed=False, stream=st.cuda_stream)
+        # first use of a stream is not free (~5 ms): one launch on it outside the timed region, whatever --warmup says
+        panel.run(burnin=0, seed=1234, window_base=ids[0], threads_per_window=args.threads_per_window, timed=False, stream=st.cuda_stream)
     fence()
     if world == 1:
         # one GPU: the K steps are enqueued back to back on one stream (no host round trip between steps: nothing on the host
