@@ -96,15 +96,22 @@ struct KernelParams {
     // the sweep's uniforms, the state maps and the states, [W][stream_stride] bytes; library-owned
     uint8_t* sscr;
     int64_t stream_stride;
-    // length-bucketed dispatch (hmcg.hip, launch_buckets): this launch runs the windows with t_lo < T[w] <= t_hi only; the
-    // blocks of every other window leave at once (another launch of the same call, with the steps-per-thread variant
-    // that fits them, runs beside this one on its own stream).  One launch for everything: INT32_MIN / INT32_MAX
-    int32_t t_lo, t_hi;
     // host entry, first launch of a call: pinned HOST memory (device-addressable), one word per window, zeroed by the host --
     // a window the prologue skips puts its status bits here as well, so that the host knows whose block of a chunk buffer
     // holds nothing without a copy of the status words (a copy that small is a shader copy in the HIP runtime: it cannot
     // start while the sweep kernels hold every CU, and the chunk's SDMA copy queued behind it waited with it).  May be null.
     int32_t* skip_host;
+    // length-bucketed dispatch (hmcg.hip, launch_kernel / bucket_lists_kernel): this launch runs the windows of ONE length class,
+    // t_lo < T[w] <= t_hi; another launch of the same call, with the steps-per-thread variant that fits them, runs the others
+    // beside it on its own stream.  order[0] = n, order[1] = t_lo, order[2] = t_hi, order[4..4+n) = the ids of the class's
+    // windows, compacted: block b runs window order[4 + b] for b < n and leaves at once otherwise.  The live blocks of a
+    // launch are then blocks 0..n-1 whatever the order of the caller's windows -- with the class's windows scattered over the
+    // grid between blocks that leave, a shuffled production batch took 9.5 ms against 6.4 sorted
+    // (profiles/r04/production_460_order.txt).  n < 0 (the lists found every class in one run of the caller's windows: a
+    // batch sorted by length, as the reference's expanding windows are): block b runs window b if its length is in the
+    // class and leaves otherwise.  Null: one launch for everything, block b runs window b.
+    // (ONE kernel argument: more fields and a loop in the prologue cost the sweep loop 2 % through the register allocator.)
+    const int32_t* order;
 };
 
 // a window the prologue refuses: its status bits, in HBM and (host entry) in the host's skip words
@@ -912,7 +919,17 @@ void gibbs_sweeps_kernel(const KernelParams p)
     using Sh = SweepShared<K, L, NT, SIG>;
     __shared__ Sh sh;
 
-    const int w = blockIdx.x;
+    int w_ = blockIdx.x;
+    int t_lo_ = INT32_MIN, t_hi_ = INT32_MAX;
+    if (p.order) {
+        const int n_live = p.order[0];
+        t_lo_ = p.order[1]; t_hi_ = p.order[2];
+        if (n_live >= 0) {                           // (uniform) some class is scattered over the grid: run the compacted list
+            if (w_ >= n_live) __builtin_amdgcn_endpgm();
+            w_ = p.order[4 + w_];
+        }
+    }
+    const int w = w_;
 #ifdef HMCG_VECTOR_WAVE                                     // (A/B only: the wave id as a per-lane value, as until round 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #else
@@ -926,7 +943,7 @@ void gibbs_sweeps_kernel(const KernelParams p)
     const bool helper = NH > 0 && __builtin_amdgcn_readfirstlane(wave) >= NW;   // wave-uniform
     int st = 0;
 
-    if (T <= p.t_lo || T > p.t_hi) __builtin_amdgcn_endpgm();   // another length bucket's window: this block leaves at once
+    if (T <= t_lo_ || T > t_hi_) __builtin_amdgcn_endpgm();   // another length bucket's window: this block leaves at once
     if (T < 2 || T > NT * L || T > p.ldY) {   // uniform per block
         if (tid == 0) flag_skipped(p, w, HMCG_ST_BAD_T);
         return;
