@@ -382,7 +382,7 @@ int make_plan(const hmcg_config* cfg, const hmcg_extras* ex, int W, int cu_count
     // Length-bucketed dispatch: a batch of ragged windows (the reference's production run: 460 expanding windows of 120..579
     // months, code/run_hmm.jl:79-109) is cut by the steps-per-thread class each window needs; every class gets its own launch
     // on its own stream, all of them over the whole grid -- the blocks of the other classes' windows leave at once
-    // (KernelParams::t_lo / t_hi).  A window then runs on the variant its own length selects, whatever else the call holds:
+    // (the class bounds in the header of KernelParams::order).  A window then runs on the variant its own length selects, whatever else the call holds:
     // its result equals that of a call with this window alone, bit for bit.  (HMCG_NO_BUCKETS=1, diagnostics: one launch
     // sized for the longest window, as before round 4.)
     if (pl.v && pl.v->NT == 256 && cfg->threads_per_window == 0 && minT > 0 && minT < maxT && !diag_env("HMCG_NO_BUCKETS")) {

@@ -96,3 +96,32 @@ def test_windows_outside_the_hint_and_bad_lengths(hmclib):
     g = _lib.estimate_batch_host(Y, Tw, K, 1, 4, HOR, fut[:, [0, 11]], nan_fill=False)
     assert g["status"][3] == _lib.ST_BAD_T and (np.delete(g["status"], 3) == 0).all()
     assert g["buckets"] == 3 and not g["mu"][3].any()
+
+
+def test_shuffled_batch_equals_sorted_batch_on_both_entries(hmclib, panel460, monkeypatch):
+    """The order of the windows in a call is the caller's business: a shuffled batch (every length class scattered over the
+    grid -- the launches then run their compacted window lists, KernelParams::order) gives every window the bits it has in
+    the sorted batch (classes in one run each: block b = window b), on the host entry and on the device entry; and so does
+    a sorted batch with the compaction switched off (HMCG_NO_BUCKET_LISTS)."""
+    Y, Tw, yreal = panel460
+    W = Y.shape[0]
+    burnin, nrun = 2, 7
+    ids = np.arange(W)
+    ref = _lib.estimate_batch_host(Y, Tw, K, burnin, nrun, HOR, yreal, want_state=True, window_ids=ids)
+    assert ref["buckets"] == 3 and (ref["status"] == 0).all()
+    perm = np.random.default_rng(5).permutation(W)
+    g = _lib.estimate_batch_host(np.ascontiguousarray(Y[perm]), Tw[perm], K, burnin, nrun, HOR, np.ascontiguousarray(yreal[perm]),
+                                 want_state=True, window_ids=ids[perm])
+    assert g["buckets"] == 3
+    for k in NAMES + ("x_final", "status"):
+        assert np.array_equal(g[k], ref[k][perm]), k
+    p = hdev.DevicePanel(np.ascontiguousarray(Y[perm]), Tw[perm], K, nrun, HOR, np.ascontiguousarray(yreal[perm]), window_ids=ids[perm])
+    p.run(burnin=burnin)
+    assert p.last_timing.buckets == 3
+    assert np.array_equal(p.mu.cpu().numpy(), ref["mu"][perm]) and np.array_equal(p.summary.cpu().numpy(), ref["summary"][perm])
+    assert np.array_equal(p.status.cpu().numpy(), ref["status"][perm])
+    monkeypatch.setenv("HMCG_NO_BUCKET_LISTS", "1")
+    h = _lib.estimate_batch_host(np.ascontiguousarray(Y[perm]), Tw[perm], K, burnin, nrun, HOR, np.ascontiguousarray(yreal[perm]),
+                                 want_state=True, window_ids=ids[perm])
+    for k in NAMES + ("x_final", "status"):
+        assert np.array_equal(h[k], g[k]), k
